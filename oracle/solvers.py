@@ -1,0 +1,222 @@
+"""
+CPU restatement of the iterative solvers on the hot path.
+
+Test infrastructure (see oracle/__init__.py).  Follows
+  pfb/opt/pcg.py:53-136            pcg
+  pfb/opt/pcg.py:243-291           _pcg_psf_impl (per-band PSF PCG)
+  pfb/utils/misc.py:1316-1351      norm_diff
+  pfb/opt/power_method.py:11-49    power_method
+  pfb/opt/primal_dual.py:91-180    primal_dual_optimised
+  pfb/utils/misc.py:1070-1080      l1reweight_func
+
+The recurrences are written out in full so the
+semantics that matter for parity are visible: residual sign r = A x - b, the
+stopping rule, the backtracking loop that costs no extra matvec, the break on an
+all-zero search direction that does NOT increment k.
+"""
+import numpy as np
+from . import fftconv as _fc
+from . import prox as _prox
+
+
+# --------------------------------------------------------------------- misc
+def norm_diff(x, xp):
+    """misc.py:1326-1351: sqrt(sum((x-xp)^2) / (1e-12 + sum(x^2))), float64
+    accumulators, 2-D or 3-D input only."""
+    if x.ndim not in (2, 3):
+        raise ValueError("norm_diff is only implemented for 2D or 3D arrays")
+    d = x.astype(np.float64) - xp.astype(np.float64)
+    num = float(np.sum(d * d))
+    den = 1e-12 + float(np.sum(x.astype(np.float64) ** 2))
+    return np.sqrt(num / den)
+
+
+def l1reweight_func(psiH, outvar, rmsfactor, rms_comps, model, alpha=4):
+    """misc.py:1070-1080.  `psiH` is the analysis operator Psi.dot here."""
+    psiH(model, outvar)
+    mcomps = np.abs(np.sum(outvar, axis=0))
+    return (1 + rmsfactor) / (1 + mcomps ** alpha / rms_comps ** alpha)
+
+
+# ---------------------------------------------------------------------- pcg
+class PCGTrace:
+    """Optional recorder of the iterate history (used for golden vectors)."""
+
+    def __init__(self, keep=()):
+        self.keep = set(keep)
+        self.x_at = {}
+        self.eps = []
+        self.alpha = []
+        self.nbacktrack = []
+        self.k_exit = None
+        self.status = None
+
+
+def pcg(A, b, x0=None, M=None, tol=1e-5, maxit=500, minit=100, verbosity=1,
+        report_freq=10, backtrack=True, return_resid=False, trace=None):
+    """pcg.py:53-136."""
+    if x0 is None:
+        x0 = np.zeros(b.shape, dtype=b.dtype)
+    if M is None:
+        def M(v):
+            return v
+
+    r = A(x0) - b                       # pcg.py:71   residual convention A x - b
+    y = M(r)
+    if not np.any(y):                   # pcg.py:73-75  early exit returns x0 ONLY
+        if trace is not None:
+            trace.status = 'zero-residual'
+            trace.k_exit = 0
+        return x0
+    p = -y
+    rnorm = np.vdot(r, y)
+    k = 0
+    x = x0
+    eps = 1.0
+    status = None
+    while (eps > tol or k < minit) and k < maxit:   # stall_count is inert
+        xp = x.copy()
+        rp = r.copy()
+        Ap = A(p)                       # the one matvec per iteration
+        rnorm = np.vdot(r, y)
+        alpha = rnorm / np.vdot(p, Ap)
+        x = xp + alpha * p
+        r = rp + alpha * Ap
+        y = M(r)
+        rnorm_next = np.vdot(r, y)
+        nbt = 0
+        while rnorm_next > rnorm and backtrack:     # pcg.py:96-101
+            alpha *= 0.75
+            x = xp + alpha * p
+            r = rp + alpha * Ap
+            y = M(r)
+            rnorm_next = np.vdot(r, y)
+            nbt += 1
+        beta = rnorm_next / rnorm
+        p = beta * p - y
+        if not np.any(p):               # pcg.py:106-107: break BEFORE k += 1
+            status = 'breakdown'
+            break
+        rnorm = rnorm_next
+        k += 1
+        eps = norm_diff(x, xp)
+        if trace is not None:
+            trace.eps.append(float(eps))
+            trace.alpha.append(float(alpha))
+            trace.nbacktrack.append(nbt)
+            if k in trace.keep:
+                trace.x_at[k] = x.copy()
+
+    if trace is not None:
+        trace.k_exit = k
+        trace.status = status or ('maxit' if k >= maxit else 'converged')
+    if not return_resid:
+        return x
+    return x, r
+
+
+def pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, sigmainv, cgopts):
+    """pcg.py:243-360 without the dask wrapping: independent PCG per band with
+    A = _hessian_psf_slice(psfhat[k], beam[k], sigmainv), M = x/sigmainv."""
+    nband, nx, ny = b.shape
+    if beam is not None:
+        if beam.ndim == 2:
+            beam = beam[None]
+        if beam.shape[0] == 1:
+            beam = np.tile(beam, (nband, 1, 1))
+        elif beam.shape[0] != nband:
+            raise ValueError('Beam has incorrect shape')
+    model = np.zeros((nband, nx, ny), dtype=b.dtype)
+    if sigmainv > 0:
+        def M(v):
+            return v / sigmainv
+    else:
+        M = None
+    for k in range(nband):
+        xpad, xhat, xout = _fc.make_scratch(psfhat[k], lastsize, (nx, ny), b.dtype)
+        bk = None if beam is None else beam[k]
+
+        def A(v, xpad=xpad, xhat=xhat, xout=xout, k=k, bk=bk):
+            return _fc._hessian_psf_slice(xpad, xhat, xout, psfhat[k], bk, lastsize,
+                                          v, nthreads=nthreads, sigmainv=sigmainv)
+        model[k] = pcg(A, b[k], x0[k], M=M, **cgopts)
+    return model
+
+
+# ------------------------------------------------------------- power method
+def power_method(A, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1,
+                 report_freq=25):
+    """power_method.py:11-49.  A may return an aliased buffer that is normalised
+    in place (power_method.py:29-36); b0=None draws an unseeded randn start."""
+    if b0 is None:
+        b = np.random.randn(*imsize)
+        b /= np.linalg.norm(b)
+    else:
+        b = b0 / np.linalg.norm(b0)
+    beta = 1.0
+    eps = 1.0
+    k = 0
+    bp = b.copy()
+    while eps > tol and k < maxit:
+        b = A(bp)
+        bnorm = np.linalg.norm(b)
+        betap = beta
+        beta = np.vdot(bp, b) / np.vdot(bp, bp)
+        b /= bnorm
+        eps = np.linalg.norm(beta - betap) / betap
+        k += 1
+        bp[...] = b[...]
+    return beta, b
+
+
+# -------------------------------------------------------------- primal dual
+def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, grad,
+                          nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000,
+                          positivity=1, report_freq=10, gamma=1.0, verbosity=1,
+                          maxreweight=50, trace=None):
+    """primal_dual.py:91-180.
+
+    Naming trap kept from the reference: the 4th positional `psiH` receives the
+    SYNTHESIS operator (Psi.hdot) and the 5th `psi` the ANALYSIS operator (Psi.dot)
+    at the call site (workers/spotless.py:268-269).  `prox` is accepted and unused.
+    Where the reference drops into pdb (x all zero -> eps = 1.0, NaN eps) we just
+    carry on with the same values.
+    """
+    xp = x.copy()
+    vp = v.copy()
+    xout = np.zeros_like(x)        # NB: x and v are updated IN PLACE (out=x, psi(xp, v))
+    if sigma is None:
+        sigma = L / (2.0 * gamma) / nu
+    tau = 0.9 / (L / (2.0 * gamma) + sigma * nu ** 2)
+
+    eps = 1.0
+    numreweight = 0
+    k_exit = maxit
+    for k in range(maxit):
+        psi(xp, v)                                        # analysis into v
+        _prox.dual_update_numba(vp, v, lam, sigma=sigma, weight=l1weight)
+        vp[...] = 2.0 * v - vp                            # primal_dual.py:137
+        psiH(vp, xout)                                    # synthesis into xout
+        xout += grad(xp)
+        x[...] = xp - tau * xout                          # primal_dual.py:140
+        if positivity == 1:
+            x[x < 0.0] = 0.0
+        elif positivity == 2:
+            msk = np.any(x <= 0, axis=0)
+            x[:, msk] = 0.0
+        if x.any():
+            eps = norm_diff(x, xp)
+        else:
+            eps = 1.0
+        if trace is not None:
+            trace.append(float(eps))
+        if eps < tol:
+            if reweighter is not None and numreweight < maxreweight:
+                l1weight = reweighter(x)
+                numreweight += 1
+            else:
+                k_exit = k
+                break
+        xp[...] = x[...]
+        vp[...] = v[...]
+    return x, v

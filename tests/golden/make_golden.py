@@ -1,0 +1,290 @@
+#!/usr/bin/env python
+"""
+Golden-vector generator: runs the REFERENCE's own source files
+(/root/reference/pfb/{operators/psf,operators/hessian,opt/pcg,opt/power_method,
+opt/primal_dual,operators/psi,wavelets/wavelets,prox/prox_21m,prox/prox_21}.py) under
+the stub third-party modules of _refstubs.py and stores inputs + reference outputs
+as small .npz fixtures next to this file.
+
+Run in the BUILD container only:   python tests/golden/make_golden.py
+(/root/reference is absent on the GPU box; the tests only read the .npz files.)
+
+Seeds: numpy.random.default_rng(420 + case index); 420 is the reference's own test
+seed (tests/test_spotless.py:18).
+"""
+import os
+import sys
+from functools import partial
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import _refstubs  # noqa: E402
+
+_refstubs.install(ROOT)
+
+from pfb.operators.psf import psf_convolve_slice, psf_convolve_cube  # noqa: E402
+from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube  # noqa: E402
+from pfb.opt.pcg import pcg, _pcg_psf_impl  # noqa: E402
+from pfb.opt.power_method import power_method  # noqa: E402
+from pfb.opt.primal_dual import primal_dual_optimised  # noqa: E402
+from pfb.operators.psi import Psi  # noqa: E402
+from pfb.prox.prox_21m import (prox_21m, prox_21m_numba, dual_update,  # noqa: E402
+                               dual_update_numba)
+from pfb.prox.prox_21 import prox_21  # noqa: E402
+import scipy.fft as sfft  # noqa: E402
+
+
+def rand_psfhat(rng, nb, P, Q, dtype=np.float64):
+    """Random NON-symmetric real PSF peaked at the centre -> complex psfhat
+    (gridder.py:712: r2c(ifftshift(psf)))."""
+    psf = 0.05 * rng.standard_normal((nb, P, Q))
+    u = (np.arange(P) - P // 2)[:, None]
+    v = (np.arange(Q) - Q // 2)[None, :]
+    psf += np.exp(-(u ** 2 + v ** 2) / (2 * 2.5 ** 2))[None]
+    psf = psf.astype(dtype)
+    psfhat = sfft.rfftn(sfft.ifftshift(psf, axes=(1, 2)), axes=(1, 2))
+    return psf, psfhat
+
+
+def psd_psfhat(rng, nb, P, Q):
+    """PSD operator: psfhat = non-negative uv weights, sum_b psf peaks at 1."""
+    u = sfft.fftfreq(P)[:, None]
+    v = sfft.rfftfreq(Q)[None, :]
+    lam = 4 * np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2))
+    W = rng.poisson(lam, size=(nb, P, Q // 2 + 1)).astype(np.float64)
+    psf = sfft.irfftn(W, s=(P, Q), axes=(1, 2))
+    W /= nb * psf.max(axis=(1, 2))[:, None, None]
+    return W.astype(np.complex128)
+
+
+def scratch(psfhat, Q, shape):
+    if psfhat.ndim == 2:
+        P, nyo2 = psfhat.shape
+        return (np.empty((P, Q)), np.empty((P, nyo2), dtype=psfhat.dtype),
+                np.empty(shape))
+    nb, P, nyo2 = psfhat.shape
+    return (np.empty((nb, P, Q)), np.empty((nb, P, nyo2), dtype=psfhat.dtype),
+            np.empty(shape))
+
+
+def gen_conv():
+    out = {}
+    cases = [(32, 32, 64, 64), (48, 40, 96, 80), (64, 64, 128, 128),
+             (32, 32, 48, 40), (30, 50, 60, 100), (16, 128, 32, 256)]
+    out['cases'] = np.array(cases)
+    for c, (nx, ny, P, Q) in enumerate(cases):
+        rng = np.random.default_rng(420 + c)
+        nb = 2
+        psf, psfhat = rand_psfhat(rng, nb, P, Q)
+        x = rng.standard_normal((nb, nx, ny))
+        beam = 0.5 + rng.random((nb, nx, ny))
+        # slice
+        xpad, xhat, xout = scratch(psfhat[0], Q, (nx, ny))
+        ys = psf_convolve_slice(xpad, xhat, xout, psfhat[0], Q, x[0]).copy()
+        # cube
+        xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+        yc = psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x).copy()
+        # hessians: beam+wsum+sigmainv, and bare
+        xpad, xhat, xout = scratch(psfhat[1], Q, (nx, ny))
+        h1 = _hessian_psf_slice(xpad, xhat, xout, psfhat[1], beam[1], Q, x[1],
+                                nthreads=1, sigmainv=0.37, wsum=2.5).copy()
+        h2 = _hessian_psf_slice(xpad, xhat, xout, psfhat[1], None, Q, x[1],
+                                nthreads=1, sigmainv=0.0, wsum=None).copy()
+        xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+        h3 = hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, x,
+                              nthreads=1, sigmainv=1.25, wsum=3.0).copy()
+        h4 = hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, x,
+                              nthreads=1, sigmainv=0.5, wsum=None).copy()
+        out.update({f'c{c}_psf': psf, f'c{c}_psfhat': psfhat, f'c{c}_x': x,
+                    f'c{c}_beam': beam, f'c{c}_slice': ys, f'c{c}_cube': yc,
+                    f'c{c}_h_slice_full': h1, f'c{c}_h_slice_bare': h2,
+                    f'c{c}_h_cube_full': h3, f'c{c}_h_cube_bare': h4})
+    np.savez_compressed(os.path.join(HERE, 'conv.npz'), **out)
+    print('conv.npz', len(out))
+
+
+def gen_pcg():
+    out = {}
+    rng = np.random.default_rng(431)
+    nb, nx, ny, P, Q = 3, 48, 40, 96, 80
+    psfhat = psd_psfhat(rng, nb, P, Q)
+    model = np.zeros((nb, nx, ny))
+    for _ in range(6):
+        i, j = rng.integers(5, nx - 5), rng.integers(5, ny - 5)
+        model[:, i, j] = 1 + np.exp(rng.standard_normal())
+    yy, xx = np.meshgrid(np.arange(ny), np.arange(nx))
+    model += 0.5 * np.exp(-((xx - 20) ** 2 + (yy - 22) ** 2) / 18.0)[None]
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    b = psf_convolve_cube(xpad, xhat, xout, psfhat, Q, model).copy()
+    b += 1e-3 * rng.standard_normal(b.shape)
+    beam = 0.7 + 0.3 * np.exp(-((xx - nx / 2) ** 2 + (yy - ny / 2) ** 2) / 400.0)
+    beam = np.tile(beam[None], (nb, 1, 1))
+    sigmainv = 1e-3 * np.abs(b).max()
+    out.update(psfhat=psfhat, b=b, beam=beam, sigmainv=sigmainv, Q=Q)
+
+    # (1) per-band PCG (klean flux-mop semantics, pcg.py:243-291), iterate history
+    for tag, bm in (('nobeam', None), ('beam', beam)):
+        for k in (1, 2, 5, 20):
+            for bt in (True, False):
+                m = _pcg_psf_impl(psfhat, b, np.zeros_like(b),
+                                  bm if bm is not None else [None] * nb, Q, 1, sigmainv,
+                                  tol=0.0, maxit=k, minit=k, verbosity=0,
+                                  backtrack=bt)
+                out[f'band_{tag}_k{k}_bt{int(bt)}'] = m
+    # convergence-controlled exit (tol hit before maxit; minit forcing)
+    m = _pcg_psf_impl(psfhat, b, np.zeros_like(b), [None] * nb, Q, 1, sigmainv,
+                      tol=1e-2, maxit=100, minit=1, verbosity=0, backtrack=True)
+    out['band_tol1e-2'] = m
+    m = _pcg_psf_impl(psfhat, b, np.zeros_like(b), [None] * nb, Q, 1, sigmainv,
+                      tol=1e-2, maxit=100, minit=15, verbosity=0, backtrack=True)
+    out['band_tol1e-2_minit15'] = m
+
+    # (2) cube PCG with global dots (fluxmop semantics, fluxmop.py:160-199)
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    A = partial(hessian_psf_cube, xpad, xhat, xout, beam, psfhat, Q,
+                nthreads=1, sigmainv=sigmainv, wsum=1.0)
+    for k in (1, 3, 10, 25):
+        x, r = pcg(A, beam * b, np.zeros_like(b), tol=0.0, maxit=k, minit=k,
+                   verbosity=0, backtrack=True, return_resid=True)
+        out[f'cube_k{k}_x'] = x
+        out[f'cube_k{k}_r'] = r
+    # with diagonal preconditioner and non-zero x0
+    x0 = 0.1 * rng.standard_normal(b.shape)
+    out['cube_x0'] = x0
+    x = pcg(A, beam * b, x0, M=lambda v: v / sigmainv, tol=0.0, maxit=7, minit=7,
+            verbosity=0, backtrack=True)
+    out['cube_M_x0_k7'] = x
+    # zero-residual early exit returns x0 (pcg.py:73-75)
+    xz = pcg(A, A(x0).copy(), x0, tol=1e-5, maxit=5, minit=1, verbosity=0)
+    out['cube_zero_resid_is_x0'] = np.array(xz is x0)
+
+    # (3) operator for which backtracking actually triggers: indefinite "psf"
+    rng2 = np.random.default_rng(777)
+    ph = psfhat[0].copy()
+    ph -= 0.35 * ph.real.max()          # makes A indefinite -> rnorm can grow
+    xpad, xhat, xout = scratch(ph, Q, (nx, ny))
+    A2 = partial(_hessian_psf_slice, xpad, xhat, xout, ph, None, Q,
+                 nthreads=1, sigmainv=sigmainv)
+    bb = rng2.standard_normal((nx, ny))
+    out['indef_psfhat'] = ph
+    out['indef_b'] = bb
+    for bt in (True, False):
+        for k in (3, 8):
+            out[f'indef_k{k}_bt{int(bt)}'] = pcg(A2, bb, None, tol=0.0, maxit=k, minit=k,
+                                                 verbosity=0, backtrack=bt)
+
+    # (4) power method with fixed start (power_method.py:11-49)
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    conv = partial(psf_convolve_cube, xpad, xhat, xout, psfhat, Q)
+    b0 = rng.standard_normal((nb, nx, ny))
+    beta, bvec = power_method(conv, (nb, nx, ny), b0=b0.copy(), tol=1e-3, maxit=40,
+                              verbosity=0)
+    out.update(pm_b0=b0, pm_beta=beta, pm_b=bvec.copy())
+    np.savez_compressed(os.path.join(HERE, 'pcg.npz'), **out)
+    print('pcg.npz', len(out))
+
+
+def gen_psi():
+    out = {}
+    cases = [  # (nband, nx, ny, bases, nlevel)
+        (2, 128, 64, ['self', 'db1', 'db2', 'db3', 'db4', 'db5'], 2),
+        (1, 250, 78, ['self', 'db1', 'db2', 'db3', 'db4', 'db5'], 1),
+        (1, 64, 48, ['db2'], 3),
+        (1, 128, 256, ['db1', 'db4', 'db5'], 3),
+        (1, 120, 150, ['db3', 'self'], 2),
+    ]
+    out['ncases'] = len(cases)
+    for c, (nband, nx, ny, bases, nlevel) in enumerate(cases):
+        rng = np.random.default_rng(440 + c)
+        psi = Psi(nband, nx, ny, bases, nlevel, 1)
+        x = rng.standard_normal((nband, nx, ny))
+        alpha = np.full((nband, len(bases), psi.Nymax, psi.Nxmax), np.nan)
+        psi.dot(x, alpha)
+        coef_in = rng.standard_normal(alpha.shape)
+        xrec = np.full((nband, nx, ny), np.nan)
+        psi.hdot(coef_in, xrec)
+        out[f'p{c}_meta'] = np.array([nband, nx, ny, nlevel, psi.Nymax, psi.Nxmax])
+        out[f'p{c}_bases'] = np.array(bases)
+        out[f'p{c}_x'] = x
+        out[f'p{c}_alpha'] = alpha           # NaN marks never-written cells
+        out[f'p{c}_coef_in'] = coef_in
+        out[f'p{c}_xrec'] = xrec
+    np.savez_compressed(os.path.join(HERE, 'psi.npz'), **out)
+    print('psi.npz', len(out))
+
+
+def gen_prox():
+    out = {}
+    rng = np.random.default_rng(450)
+    nband, nbasis, nymax, nxmax = 3, 2, 20, 24
+    v = rng.standard_normal((nband, nbasis, nymax, nxmax))
+    v[:, 0, 3, 4] = 0.0                       # exercise the "sum == 0" branch
+    v[:, 1, 5, 6] = [1.0, -1.0, 0.0]          # sum exactly zero, entries not
+    vp = rng.standard_normal(v.shape)
+    w = rng.random((nbasis, nymax, nxmax))
+    out.update(v=v, vp=vp, w=w)
+    grid = [(1.0, 75.0), (1.0, 1.0), (1e-1, 1e-3), (1e-3, 1.0), (1e-1, 75.0), (1e-3, 1e-3)]
+    out['grid'] = np.array(grid)
+    for g, (lam, sigma) in enumerate(grid):
+        res = np.full(v.shape, np.nan)
+        prox_21m_numba(v, res, lam, sigma=sigma, weight=w)
+        out[f'g{g}_prox21m_numba'] = res
+        vv = v.copy()
+        dual_update_numba(vp, vv, lam, sigma=sigma, weight=w)
+        out[f'g{g}_dual_update_numba'] = vv
+        out[f'g{g}_prox21m'] = prox_21m(v, lam, weight=w)
+        out[f'g{g}_prox21'] = prox_21(v, lam, weight=w)
+    np.savez_compressed(os.path.join(HERE, 'prox.npz'), **out)
+    print('prox.npz', len(out))
+
+
+def gen_pd():
+    """primal_dual_optimised trajectory (primal_dual.py:91-180) with the spotless
+    call-site wiring (workers/spotless.py:259-285)."""
+    out = {}
+    rng = np.random.default_rng(460)
+    nb, nx, ny, P, Q = 2, 32, 32, 64, 64
+    bases = ['self', 'db1', 'db2']
+    nlevel = 2
+    psfhat = psd_psfhat(rng, nb, P, Q)
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    conv = partial(psf_convolve_cube, xpad, xhat, xout, psfhat, Q)
+    truth = np.zeros((nb, nx, ny))
+    truth[:, 10, 12] = 1.0
+    truth[:, 20, 8] = 0.5
+    truth[:, 15:18, 20:23] = 0.2
+    residual = conv(truth).copy() + 1e-4 * rng.standard_normal(truth.shape)
+    model = np.zeros_like(truth)
+    psi = Psi(nb, nx, ny, bases, nlevel, 1)
+    nbasis = len(bases)
+    dual = np.zeros((nb, nbasis, psi.Nymax, psi.Nxmax))
+    l1weight = np.ones((nbasis, psi.Nymax, psi.Nxmax))
+    hessnorm = 1.05 * power_method(conv, (nb, nx, ny), b0=rng.standard_normal((nb, nx, ny)),
+                                   tol=1e-4, maxit=100, verbosity=0)[0]
+    data = residual + conv(model)
+    data = data.copy()
+
+    def grad21(x):
+        return conv(x) - data
+    lam = 1e-3
+    out.update(psfhat=psfhat, residual=residual, hessnorm=hessnorm, lam=lam,
+               bases=np.array(bases), nlevel=nlevel, Q=Q, data=data)
+    for tag, pos, maxit in (('pos1_it10', 1, 10), ('pos0_it4', 0, 4), ('pos2_it6', 2, 6)):
+        x_in = model.copy()
+        v_in = dual.copy()
+        x, v = primal_dual_optimised(x_in, v_in, lam, psi.hdot, psi.dot, hessnorm,
+                                     None, l1weight, None, grad21, nu=nbasis,
+                                     tol=0.0, maxit=maxit, positivity=pos,
+                                     report_freq=100, gamma=1.0, verbosity=0)
+        out[f'{tag}_x'] = x.copy()
+        out[f'{tag}_v'] = v.copy()
+    np.savez_compressed(os.path.join(HERE, 'pd.npz'), **out)
+    print('pd.npz', len(out))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd']
+    for w in which:
+        globals()['gen_' + w]()

@@ -1,0 +1,312 @@
+"""
+Pins the CPU oracle (oracle/) against golden vectors produced by the reference's own
+source (tests/golden/make_golden.py) and against known-answer properties
+(SURVEY.md 8c).  CPU only.
+"""
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from oracle import fftconv as fc
+from oracle import solvers as sv
+from oracle import prox as px
+from oracle import wavelets as wv
+from oracle import daubechies as db
+
+pmp = pytest.mark.parametrize
+
+
+# ------------------------------------------------------------------ filters
+@pmp('K', range(1, 10))
+def test_daubechies_orthonormal(K):
+    h = db.rec_lo(K)
+    F = h.size
+    assert F == 2 * K
+    for m in range(K):
+        s = np.dot(h[:F - 2 * m], h[2 * m:])
+        assert abs(s - (1.0 if m == 0 else 0.0)) <= 1e-15
+    assert abs(h.sum() - np.sqrt(2)) <= 5e-16
+    # K vanishing moments of the high-pass
+    dl, dh, rl, rh = db.filter_bank(f'db{K}')
+    n = np.arange(F)
+    for q in range(K):
+        assert abs(np.sum(dh * n ** q)) < 1e-8 * max(1, F ** q)
+
+
+def test_db2_closed_form():
+    s3 = np.sqrt(3)
+    assert_allclose(db.rec_lo(2), np.array([1 + s3, 3 + s3, 3 - s3, 1 - s3]) / (4 * np.sqrt(2)),
+                    rtol=0, atol=3e-16)
+
+
+# --------------------------------------------------------------------- conv
+def _scratch(psfhat, Q, shape):
+    return fc.make_scratch(psfhat, Q, shape, np.float64)
+
+
+@pmp('c', range(6))
+def test_conv_and_hessian_match_reference(golden, c):
+    g = golden('conv')
+    nx, ny, P, Q = g['cases'][c]
+    psfhat, x, beam = g[f'c{c}_psfhat'], g[f'c{c}_x'], g[f'c{c}_beam']
+    assert_allclose(fc.psfhat_from_psf(g[f'c{c}_psf']), psfhat, rtol=0, atol=1e-12)
+    xpad, xhat, xout = _scratch(psfhat[0], Q, (nx, ny))
+    y = fc.psf_convolve_slice(xpad, xhat, xout, psfhat[0], Q, x[0])
+    assert y is xout                                        # aliasing contract
+    assert_allclose(y, g[f'c{c}_slice'], rtol=0, atol=1e-12)
+    xpad, xhat, xout = _scratch(psfhat, Q, x.shape)
+    assert_allclose(fc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x),
+                    g[f'c{c}_cube'], rtol=0, atol=1e-12)
+    xpad, xhat, xout = _scratch(psfhat[1], Q, (nx, ny))
+    assert_allclose(fc._hessian_psf_slice(xpad, xhat, xout, psfhat[1], beam[1], Q, x[1],
+                                          sigmainv=0.37, wsum=2.5),
+                    g[f'c{c}_h_slice_full'], rtol=0, atol=1e-12)
+    assert_allclose(fc._hessian_psf_slice(xpad, xhat, xout, psfhat[1], None, Q, x[1],
+                                          sigmainv=0.0),
+                    g[f'c{c}_h_slice_bare'], rtol=0, atol=1e-12)
+    xpad, xhat, xout = _scratch(psfhat, Q, x.shape)
+    assert_allclose(fc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, x,
+                                        sigmainv=1.25, wsum=3.0),
+                    g[f'c{c}_h_cube_full'], rtol=0, atol=1e-12)
+    assert_allclose(fc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, x,
+                                        sigmainv=0.5),
+                    g[f'c{c}_h_cube_bare'], rtol=0, atol=1e-12)
+
+
+def test_conv_is_direct_circular_convolution():
+    """Pins the DFT boundary by definition, incl. the
+    aliasing case nx_psf < 2 nx."""
+    rng = np.random.default_rng(1)
+    for (nx, ny, P, Q) in [(6, 5, 12, 10), (6, 5, 8, 6)]:
+        psf = rng.standard_normal((P, Q))
+        x = rng.standard_normal((nx, ny))
+        psfhat = fc.psfhat_from_psf(psf)
+        xpad, xhat, xout = _scratch(psfhat, Q, (nx, ny))
+        y = fc.psf_convolve_slice(xpad, xhat, xout, psfhat, Q, x)
+        assert_allclose(y, fc.direct_circular_convolution(psf, x), rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------------- pcg
+def test_pcg_band_history(golden):
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    for tag, bm in (('nobeam', None), ('beam', beam)):
+        for k in (1, 2, 5, 20):
+            for bt in (True, False):
+                m = sv.pcg_psf(psfhat, b, np.zeros_like(b), bm, Q, 1, sigmainv,
+                               dict(tol=0.0, maxit=k, minit=k, verbosity=0, backtrack=bt))
+                ref = g[f'band_{tag}_k{k}_bt{int(bt)}']
+                assert_allclose(m, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+    for key, minit in (('band_tol1e-2', 1), ('band_tol1e-2_minit15', 15)):
+        m = sv.pcg_psf(psfhat, b, np.zeros_like(b), None, Q, 1, sigmainv,
+                       dict(tol=1e-2, maxit=100, minit=minit, verbosity=0, backtrack=True))
+        assert_allclose(m, g[key], rtol=1e-9, atol=1e-11 * np.abs(g[key]).max())
+
+
+def test_pcg_cube_and_edge_cases(golden):
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    xpad, xhat, xout = _scratch(psfhat, Q, b.shape)
+
+    def A(v):
+        return fc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, v,
+                                   sigmainv=sigmainv, wsum=1.0)
+    for k in (1, 3, 10, 25):
+        x, r = sv.pcg(A, beam * b, np.zeros_like(b), tol=0.0, maxit=k, minit=k,
+                      verbosity=0, return_resid=True)
+        assert_allclose(x, g[f'cube_k{k}_x'], rtol=1e-9, atol=1e-11)
+        assert_allclose(r, g[f'cube_k{k}_r'], rtol=1e-8, atol=1e-11)
+    x0 = g['cube_x0']
+    x = sv.pcg(A, beam * b, x0, M=lambda v: v / sigmainv, tol=0.0, maxit=7, minit=7,
+               verbosity=0)
+    assert_allclose(x, g['cube_M_x0_k7'], rtol=1e-9, atol=1e-11)
+    assert bool(g['cube_zero_resid_is_x0'])
+    xz = sv.pcg(A, A(x0).copy(), x0, tol=1e-5, maxit=5, minit=1, verbosity=0)
+    assert xz is x0
+
+
+def test_pcg_backtracking_branch(golden):
+    """Indefinite operator: the backtracking loop is taken (pcg.py:96-101)."""
+    g = golden('pcg')
+    ph, bb = g['indef_psfhat'], g['indef_b']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    xpad, xhat, xout = _scratch(ph, Q, bb.shape)
+
+    def A(v):
+        return fc._hessian_psf_slice(xpad, xhat, xout, ph, None, Q, v, sigmainv=sigmainv)
+    ntaken = 0
+    for bt in (True, False):
+        for k in (3, 8):
+            tr = sv.PCGTrace()
+            x = sv.pcg(A, bb, None, tol=0.0, maxit=k, minit=k, verbosity=0, backtrack=bt,
+                       trace=tr)
+            ref = g[f'indef_k{k}_bt{int(bt)}']
+            assert_allclose(x, ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+            ntaken += sum(tr.nbacktrack)
+    assert ntaken > 0
+    assert not np.allclose(g['indef_k8_bt1'], g['indef_k8_bt0'])
+
+
+def test_power_method(golden):
+    g = golden('pcg')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    b0 = g['pm_b0']
+    xpad, xhat, xout = _scratch(psfhat, Q, b0.shape)
+
+    def conv(v):
+        return fc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, v)
+    beta, bvec = sv.power_method(conv, b0.shape, b0=b0.copy(), tol=1e-3, maxit=40)
+    assert_allclose(beta, g['pm_beta'], rtol=1e-12)
+    assert_allclose(bvec, g['pm_b'], rtol=0, atol=1e-12)
+
+
+def test_norm_diff_contract():
+    rng = np.random.default_rng(3)
+    x, xp = rng.standard_normal((2, 4, 5)), rng.standard_normal((2, 4, 5))
+    assert_allclose(sv.norm_diff(x, xp),
+                    np.sqrt(np.sum((x - xp) ** 2) / (1e-12 + np.sum(x ** 2))), rtol=1e-15)
+    with pytest.raises(ValueError):
+        sv.norm_diff(x[0, 0], xp[0, 0])
+    assert sv.norm_diff(np.zeros((3, 3)), np.zeros((3, 3))) == 0.0
+
+
+# ------------------------------------------------------------------ wavelets
+def test_psi_matches_reference(golden):
+    g = golden('psi')
+    for c in range(int(g['ncases'])):
+        nband, nx, ny, nlevel, Nymax, Nxmax = g[f'p{c}_meta']
+        bases = [str(s) for s in g[f'p{c}_bases']]
+        psi = wv.Psi(nband, nx, ny, bases, nlevel, 1)
+        assert (psi.Nymax, psi.Nxmax) == (Nymax, Nxmax)
+        ref = g[f'p{c}_alpha']
+        alpha = np.full(ref.shape, np.nan)
+        psi.dot(g[f'p{c}_x'], alpha)
+        # identical never-written cells, identical values elsewhere
+        assert np.array_equal(np.isnan(alpha), np.isnan(ref))
+        m = ~np.isnan(ref)
+        assert_allclose(alpha[m], ref[m], rtol=0, atol=1e-13)
+        xrec = np.full((nband, nx, ny), np.nan)
+        psi.hdot(g[f'p{c}_coef_in'], xrec)
+        assert_allclose(xrec, g[f'p{c}_xrec'], rtol=0, atol=1e-12)
+
+
+@pmp("nx", [128, 250])
+@pmp("ny", [64, 78])
+@pmp("nband", [1, 3])
+@pmp("nlevels", [1, 2])
+def test_psi_perfect_reconstruction(nx, ny, nband, nlevels):
+    """reference tests/test_psi_operator.py:14-48 (garbage-initialised outputs)."""
+    rng = np.random.default_rng(420)
+    image = rng.standard_normal((nx, ny))
+    nu = 1.0 + 0.1 * np.arange(nband)
+    x = image[None] * nu[:, None, None] ** (-0.7)
+    bases = ['self', 'db1', 'db2', 'db3', 'db4', 'db5']
+    psi = wv.Psi(nband, nx, ny, bases, nlevels, 1)
+    alpha = rng.standard_normal((nband, len(bases), psi.Nymax, psi.Nxmax))
+    xrec = rng.standard_normal((nband, nx, ny))
+    psi.dot(x, alpha)
+    psi.hdot(alpha, xrec)
+    assert_allclose(len(bases) * x, xrec, rtol=0, atol=1e-12)
+
+
+@pmp("wavelet", ["db1", "db4", "db5"])
+@pmp("shape", [(128, 256), (512, 128)])
+@pmp("nlevel", [1, 2, 3])
+def test_dwt_idwt_roundtrip(wavelet, shape, nlevel):
+    """reference tests/test_wavelets.py:11-82 (the pywt layout half of that test is
+    covered by the golden comparison above: pywt is not installed)."""
+    rng = np.random.default_rng(5)
+    nx, ny = shape
+    data = rng.random(shape)
+    F = 2 * int(wavelet[-1])
+    bk = wv.Bookkeeping(nx, ny, F, nlevel)
+    dl, dh, rl, rh = db.filter_bank(wavelet)
+    coeffs = np.zeros((bk.Ntoty, bk.Ntotx))
+    wv.dwt2d(data, coeffs, bk, dl, dh)
+    rec = np.zeros(shape)
+    wv.idwt2d(coeffs, rec, bk, rl, rh)
+    assert_allclose(rec, data, rtol=0, atol=1e-12)
+
+
+def test_psi_adjoint():
+    rng = np.random.default_rng(9)
+    nband, nx, ny = 2, 64, 48
+    bases = ['self', 'db2', 'db4']
+    psi = wv.Psi(nband, nx, ny, bases, 2, 1)
+    x = rng.standard_normal((nband, nx, ny))
+    a = np.zeros((nband, 3, psi.Nymax, psi.Nxmax))
+    psi.dot(x, a)
+    c = rng.standard_normal(a.shape)
+    written = np.full(a.shape, np.nan)
+    psi.dot(x, written)
+    c[np.isnan(written)] = 0.0
+    y = np.zeros_like(x)
+    psi.hdot(c, y)
+    assert_allclose(np.vdot(a, c), np.vdot(x, y), rtol=1e-12)
+
+
+def test_psi_level_error():
+    with pytest.raises(ValueError):
+        wv.Psi(1, 16, 16, ['db5'], 3, 1)
+
+
+# --------------------------------------------------------------------- prox
+def test_prox_matches_reference(golden):
+    g = golden('prox')
+    v, vp, w = g['v'], g['vp'], g['w']
+    for i, (lam, sigma) in enumerate(g['grid']):
+        res = np.full(v.shape, np.nan)
+        px.prox_21m_numba(v, res, lam, sigma=sigma, weight=w)
+        assert_allclose(res, g[f'g{i}_prox21m_numba'], rtol=1e-13, atol=1e-15)
+        vv = v.copy()
+        px.dual_update_numba(vp, vv, lam, sigma=sigma, weight=w)
+        assert_allclose(vv, g[f'g{i}_dual_update_numba'], rtol=1e-13, atol=1e-14)
+        assert_allclose(px.prox_21m(v, lam, weight=w), g[f'g{i}_prox21m'], rtol=1e-13, atol=1e-15)
+        assert_allclose(px.prox_21(v, lam, weight=w), g[f'g{i}_prox21'], rtol=1e-13, atol=1e-15)
+        # reference tests/test_psi_operator.py:126-147
+        assert_allclose(px.prox_21m(v / sigma, lam / sigma, weight=w), res, atol=1e-8)
+
+
+def test_dual_update_identity():
+    """reference tests/test_psi_operator.py:150-193: dual_update_numba ==
+    vtilde - sigma*prox_21m(vtilde/sigma, lam/sigma)."""
+    rng = np.random.default_rng(11)
+    nband, nx, ny = 3, 120, 150
+    bases = ['self', 'db1', 'db3']
+    psi = wv.Psi(nband, nx, ny, bases, 2, 1)
+    w = rng.random((3, psi.Nymax, psi.Nxmax))
+    x = rng.standard_normal((nband, nx, ny))
+    for lam, sigma in [(1.0, 75.0), (1e-1, 1.0), (1e-3, 1e-3)]:
+        v = np.zeros((nband, 3, psi.Nymax, psi.Nxmax))
+        psi.dot(rng.standard_normal(x.shape), v)
+        vp = v.copy()
+        res1 = px.dual_update(v, x, psi.dot, lam, sigma=sigma, weight=w)
+        psi.dot(x, v)
+        px.dual_update_numba(vp, v, lam, sigma=sigma, weight=w)
+        assert_allclose(1 + res1, 1 + v, rtol=0, atol=1e-9)
+
+
+# -------------------------------------------------------------- primal dual
+def test_primal_dual_trajectory(golden):
+    g = golden('pd')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx = ny = P // 2
+    bases = [str(s) for s in g['bases']]
+    psi = wv.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    xpad, xhat, xout = _scratch(psfhat, Q, (nb, nx, ny))
+    data = g['data']
+
+    def grad21(x):
+        return fc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x) - data
+    l1w = np.ones((len(bases), psi.Nymax, psi.Nxmax))
+    for tag, pos, maxit in (('pos1_it10', 1, 10), ('pos0_it4', 0, 4), ('pos2_it6', 2, 6)):
+        x0 = np.zeros((nb, nx, ny))
+        v0 = np.zeros((nb, len(bases), psi.Nymax, psi.Nxmax))
+        x, v = sv.primal_dual_optimised(x0, v0, float(g['lam']), psi.hdot, psi.dot,
+                                        float(g['hessnorm']), None, l1w, None, grad21,
+                                        nu=len(bases), tol=0.0, maxit=maxit, positivity=pos)
+        assert_allclose(x, g[f'{tag}_x'], rtol=1e-9, atol=1e-12)
+        assert_allclose(v, g[f'{tag}_v'], rtol=1e-9, atol=1e-12)
