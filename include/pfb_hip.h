@@ -1,0 +1,195 @@
+/*
+ * pfb_hip.h -- C-ABI of libpfb_hip.so: the MI355X (gfx950) implementation of the
+ * pfb-imaging PCG / PSF-convolution / wavelet hot path.
+ *
+ * The reference (ratt-ru/pfb-imaging 0.0.4) is pure Python and has no FFI of its own;
+ * its boundary is the set of Python callables the workers import.  Each
+ * entry point below names the reference function (file:line under /root/reference)
+ * whose arithmetic it replaces; pfb_clean_amd/{operators,opt,prox,wavelets,utils}
+ * re-export the reference's Python names on top of these and INTEGRATION.md shows
+ * the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns an int status (PFB_OK = 0, negative = error) and never
+ *     throws; pfb_last_error() gives a thread-local message for the last failure;
+ *   - all array arguments are DEVICE pointers (hipMalloc / torch-ROCm storage),
+ *     C-contiguous, in the dtype named by `dtype` (real arrays) or its complex pair
+ *     (interleaved re,im);
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises the device
+ *     except functions documented to (the *_solve drivers read scalars back);
+ *   - the library never allocates caller-visible memory: plans own their twiddles /
+ *     re-laid-out PSF / workspaces, callers own every vector;
+ *   - one plan may be used by one stream at a time; distinct plans are independent
+ *     and there is no global mutable state (re-entrant like the reference, which
+ *     dask may call from several threads, pcg.py:346-356).
+ */
+#ifndef PFB_HIP_H
+#define PFB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFB_ABI_VERSION 1
+
+/* dtype of the real arrays; complex arrays use the matching complex type */
+#define PFB_F32 0
+#define PFB_F64 1
+
+/* status codes */
+#define PFB_OK               0
+#define PFB_ERR_INVALID     -1   /* bad argument (null pointer, shape mismatch ...)      */
+#define PFB_ERR_UNSUPPORTED -2   /* size / radix / dtype outside the supported set       */
+#define PFB_ERR_HIP         -3   /* a HIP runtime call failed                            */
+#define PFB_ERR_NONFINITE   -4   /* NaN/Inf met where the reference drops into pdb       */
+#define PFB_ERR_ALLOC       -5   /* device allocation for a plan failed                  */
+
+/* pcg exit status (written to pfb_pcg_result.status) */
+#define PFB_PCG_CONVERGED     0  /* "Success, converged after k iterations" pcg.py:131-132 */
+#define PFB_PCG_MAXIT         1  /* "Max iters reached"                    pcg.py:124-126 */
+#define PFB_PCG_ZERO_RESIDUAL 2  /* "Initial residual is zero": x0 returned pcg.py:73-75  */
+#define PFB_PCG_BREAKDOWN     3  /* search direction became all-zero       pcg.py:106-107 */
+
+int         pfb_abi_version(void);
+const char* pfb_last_error(void);
+
+/* ------------------------------------------------------------------ PSF convolution
+ * Replaces pfb/operators/psf.py:11-29 (psf_convolve_slice), :32-56 (psf_convolve_cube)
+ * and the Tikhonov-regularised wrappers pfb/operators/hessian.py:129-158
+ * (_hessian_psf_slice) and :254-281 (hessian_psf_cube):
+ *
+ *   out = [beam *] crop( irfft2( rfft2( pad([beam *] x) ) * psfhat ) ) [/ wsum]
+ *         + sigmainv * x
+ *
+ * rfft2 unnormalised (ducc0 r2c inorm=0), irfft2 scaled by 1/(nx_psf*ny_psf) (c2r
+ * inorm=2, lastsize=ny_psf), imaginary parts of the DC / Nyquist bins of the last
+ * axis ignored like ducc0/pocketfft do.
+ */
+typedef struct pfb_conv_plan pfb_conv_plan;
+
+/* nx,ny: image; nx_psf,ny_psf(=lastsize): padded PSF grid, ny_psf even,
+ * nx <= nx_psf, ny <= ny_psf; every 1-D length must factor into {2,3,5,7,11,13}.
+ * nband: leading (imaging band) axis of the cubes this plan serves. */
+int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband,
+                            int dtype, pfb_conv_plan** plan);
+int pfb_psfconv_plan_destroy(pfb_conv_plan* plan);
+
+/* psfhat: (nband, nx_psf, ny_psf/2+1) complex, as produced by
+ * pfb/operators/gridder.py:712-714 (r2c(ifftshift(psf))) and divided by wsum in
+ * pfb/utils/misc.py:721-723.  Copied into the plan's own layout (once). */
+int pfb_psfconv_set_psfhat(pfb_conv_plan* plan, const void* psfhat, void* stream);
+
+/* Apply to bands [band0, band0+nb) of the plan.  x, out: (nb, nx, ny) real; out may
+ * not alias x.  beam: (nb, nx, ny) or NULL.  wsum <= 0 means "no division"
+ * (reference wsum=None).  sigmainv may be 0.
+ * If dot_with != NULL (same shape as x) the fp64 sum over all nb bands of
+ * dot_with*out is written to *dot_out (device double) -- the fused p.Ap of
+ * pcg.py:91.  Asynchronous on `stream`. */
+int pfb_psfconv_apply(pfb_conv_plan* plan, int band0, int nb,
+                      const void* x, const void* beam, double wsum, double sigmainv,
+                      void* out, const void* dot_with, double* dot_out, void* stream);
+
+/* Introspection for benchmarks / tests */
+int    pfb_psfconv_plan_info(const pfb_conv_plan* plan, int* fast_path, int* vb,
+                             size_t* workspace_bytes);
+
+/* ------------------------------------------------------------- CG vector kernels
+ * Fused replacements for the numpy passes of pfb/opt/pcg.py:77-111 and
+ * pfb/utils/misc.py:1316-1351 (norm_diff).  `ws` is a caller-provided device
+ * scratch of at least PFB_REDUCE_WS_DOUBLES doubles; results are device doubles,
+ * accumulated in fp64 in a fixed (deterministic) order. */
+#define PFB_REDUCE_WS_DOUBLES 8192
+
+/* out[0] = sum a*b                                   (np.vdot on real arrays) */
+int pfb_dot(int dtype, const void* a, const void* b, size_t n,
+            double* out, double* ws, void* stream);
+/* out[0] = sum (x-xp)^2, out[1] = sum x^2            (norm_diff partial sums) */
+int pfb_norm_diff_sums(int dtype, const void* x, const void* xp, size_t n,
+                       double* out, double* ws, void* stream);
+/* out[0] = 1.0 if any element of a is non-zero else 0.0   (np.any) */
+int pfb_any_nonzero(int dtype, const void* a, size_t n, double* out, double* ws,
+                    void* stream);
+/* y = a*x + b*y elementwise (a, b host scalars) */
+int pfb_axpby(int dtype, double a, const void* x, double b, void* y, size_t n,
+              void* stream);
+
+/* -------------------------------------------------------------------- fused PCG
+ * Replaces pfb/opt/pcg.py:53-136 (pcg) for the operator
+ *   A(x) = hessian_psf(plan, beam, wsum, sigmainv)           (hessian.py:129-158/254-281)
+ * and the preconditioner M(r) = r / mdiv (mdiv = sigmainv as pcg.py:264-267;
+ * mdiv <= 0 means M = identity).  NaN/Inf propagate silently exactly as in the reference.
+ * Works on bands [band0, band0+nb) as ONE system (np.vdot over the whole cube, the
+ * fluxmop semantics fluxmop.py:193-199); call once per band for pcg_psf semantics.
+ *
+ * allreduce: optional hook for band-sharded multi-GPU solves -- called on `stream`
+ * order with a device buffer of `count` doubles that must be summed in place over
+ * all ranks (RCCL); NULL for single-GPU.
+ */
+typedef int (*pfb_allreduce_fn)(void* ctx, double* dev_buf, int count, void* stream);
+
+typedef struct {
+    int    status;       /* PFB_PCG_* */
+    int    iters;        /* k at exit */
+    int    matvecs;      /* number of A applications (k + 1 unless early exit) */
+    int    backtracks;   /* total backtracking steps taken */
+    double eps;          /* last norm_diff(x, xp) */
+    double rnorm;        /* last r.y */
+} pfb_pcg_result;
+
+/* b, x: (nb, nx, ny).  x holds x0 on entry and the solution on exit (for
+ * PFB_PCG_ZERO_RESIDUAL it is left untouched = x0, as the reference returns x0).
+ * r_out: optional (nb,nx,ny) residual A x - b on exit (return_resid=True).
+ * work: device scratch of pfb_pcg_work_bytes() bytes.
+ * Synchronises `stream` (reads scalars back once per iteration). */
+size_t pfb_pcg_work_bytes(const pfb_conv_plan* plan, int nb);
+int pfb_pcg_solve(pfb_conv_plan* plan, int band0, int nb,
+                  const void* b, void* x, void* r_out,
+                  const void* beam, double wsum, double sigmainv, double mdiv,
+                  double tol, int maxit, int minit, int backtrack,
+                  void* work, pfb_allreduce_fn allreduce, void* allreduce_ctx,
+                  pfb_pcg_result* result, void* stream);
+
+/* ----------------------------------------------------------- wavelets / prox / PD
+ * Replaces pfb/wavelets/wavelets.py:175-213 (dwt2d), :261-315 (idwt2d) and
+ * pfb/operators/psi.py:187-256 (psi_band.dot / hdot) over all (band, basis) pairs.
+ * Coefficient cube layout identical to the reference: (nband, nbasis, Nymax, Nxmax),
+ * each basis block transposed (y-major) in [0:Ntoty, 0:Ntotx]; cells outside the
+ * union of level blocks are neither written by dot nor read by hdot.
+ */
+typedef struct pfb_psi_plan pfb_psi_plan;
+
+/* basis_k[i] = 0 for 'self', K for 'dbK' (1..9).  filters: nbasis*4*18 doubles,
+ * [basis][dec_lo,dec_hi,rec_lo,rec_hi][tap] (unused taps 0), the table PyWavelets
+ * would supply (psi.py:37-43). */
+int pfb_psi_plan_create(int nband, int nx, int ny, int nbasis, const int* basis_k,
+                        const double* filters, int nlevel, int dtype,
+                        pfb_psi_plan** plan);
+int pfb_psi_plan_destroy(pfb_psi_plan* plan);
+int pfb_psi_plan_dims(const pfb_psi_plan* plan, int* nymax, int* nxmax);
+/* analysis  psi.py:187-218 : x (nband,nx,ny) -> alpha (nband,nbasis,Nymax,Nxmax) */
+int pfb_psi_dot(pfb_psi_plan* plan, const void* x, void* alpha, void* stream);
+/* synthesis psi.py:221-256 : alpha -> xo (nband,nx,ny), summed over bases */
+int pfb_psi_hdot(pfb_psi_plan* plan, const void* alpha, void* xo, void* stream);
+
+/* pfb/prox/prox_21m.py:76-103 dual_update_numba, in place on v.
+ * vp, v: (nband, nbasis, nymax, nxmax); weight: (nbasis, nymax, nxmax).
+ * If vp_out != NULL it additionally receives 2*v_new - vp (primal_dual.py:137). */
+int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight,
+                    double lam, double sigma, int nband, size_t nper,
+                    void* vp_out, void* stream);
+/* pfb/prox/prox_21m.py:31-61 prox_21m_numba */
+int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight,
+                 double lam, double sigma, int nband, size_t nper, void* stream);
+/* primal_dual.py:140-146: x = xp - tau*(xout + g); positivity 0|1|2 over nband;
+ * sums[0..1] receive the norm_diff partial sums of (x, xp), sums[2] = any(x). */
+int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void* g,
+                         double tau, int positivity, int nband, size_t npix,
+                         void* x, double* sums, double* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFB_HIP_H */

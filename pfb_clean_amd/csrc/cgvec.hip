@@ -1,0 +1,476 @@
+// cgvec.hip -- fused CG vector kernels, deterministic fp64 reductions and the PCG driver.
+//
+// Replaces the ~12 numpy passes per iteration of pfb/opt/pcg.py:86-122 and the
+// serial numba norm_diff (pfb/utils/misc.py:1316-1351) by three HBM-bound kernels:
+//   k_pcg_init    r = A x0 - b ; y = M r ; p = -y           + <r,y>, any(y)
+//   k_pcg_update  x' = x + a p ; r' = r + a Ap ; y' = M r'   + <r',y'>, |x'-x|^2, |x'|^2
+//   k_pcg_dir     p = beta p - M r'                          + any(p)
+// All inner products accumulate in fp64 (wave64 __shfl_down -> LDS -> one partial per
+// workgroup -> single-workgroup final sum in a fixed order), scalars stay in device
+// memory (alpha, beta are read by the kernels from there), the p.Ap product comes
+// fused out of the convolution epilogue (fftconv*.hip).
+#include "conv_plan.hpp"
+#include <cstring>
+
+namespace pfb {
+
+// scalar slots in the device state array
+enum { S_PAP = 0, S_RHON = 1, S_NUM = 2, S_DEN = 3, S_ANY = 4, S_RHO = 5, S_ALPHA = 6,
+       S_BETA = 7, S_NSCALAR = 16 };
+
+constexpr int RED_BLOCK = 256;
+constexpr int RED_MAX_GRID = 1024;
+
+static inline int red_grid(size_t nvec) {
+    size_t g = (nvec + RED_BLOCK - 1) / RED_BLOCK;
+    g = (g + 3) / 4;                      // >= 4 vectors per thread when large
+    if (g < 1) g = 1;
+    if (g > RED_MAX_GRID) g = RED_MAX_GRID;
+    return (int)g;
+}
+
+// 16-byte vector view of T
+template <typename T> struct V16;
+template <> struct V16<float>  { using type = float4;  static constexpr int N = 4; };
+template <> struct V16<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename T, int V> struct Pack { T e[V]; };
+
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld(const T* p, size_t i) {
+    Pack<T, V> r;
+    if constexpr (V == 1) {
+        r.e[0] = p[i];
+    } else {
+        using VT = typename V16<T>::type;
+        VT v = reinterpret_cast<const VT*>(p)[i];
+        memcpy(&r, &v, sizeof(VT));
+    }
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void st(T* p, size_t i, const Pack<T, V>& r) {
+    if constexpr (V == 1) {
+        p[i] = r.e[0];
+    } else {
+        using VT = typename V16<T>::type;
+        VT v;
+        memcpy(&v, &r, sizeof(VT));
+        reinterpret_cast<VT*>(p)[i] = v;
+    }
+}
+
+// write NQ block results to ws[q * gridDim.x + blockIdx.x]
+template <int NQ>
+__device__ __forceinline__ void emit_partials(double (&acc)[NQ], double* __restrict__ ws) {
+    __shared__ double red[NQ * (RED_BLOCK / 64)];
+    block_sum<NQ>(acc, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) ws[(size_t)q * gridDim.x + blockIdx.x] = acc[q];
+    }
+}
+
+// final stage: out[q] = sum_g ws[q*G + g], q < nq, fixed order
+__global__ void __launch_bounds__(RED_BLOCK)
+k_final_sum(const double* __restrict__ ws, int G, int nq, double* __restrict__ out) {
+    __shared__ double red[RED_BLOCK / 64];
+    for (int q = 0; q < nq; ++q) {
+        double acc[1] = {0.0};
+        for (int g = threadIdx.x; g < G; g += blockDim.x) acc[0] += ws[(size_t)q * G + g];
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) out[q] = acc[0];
+    }
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_dot(const T* __restrict__ a, const T* __restrict__ b, size_t nvec, double* __restrict__ ws) {
+    double acc[1] = {0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> pa = ld<T, V>(a, i), pb = ld<T, V>(b, i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[0] += (double)pa.e[e] * (double)pb.e[e];
+    }
+    emit_partials<1>(acc, ws);
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_norm_diff(const T* __restrict__ x, const T* __restrict__ xp, size_t nvec,
+            double* __restrict__ ws) {
+    double acc[2] = {0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> a = ld<T, V>(x, i), b = ld<T, V>(xp, i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const double d = (double)a.e[e] - (double)b.e[e];
+            acc[0] += d * d;
+            acc[1] += (double)a.e[e] * (double)a.e[e];
+        }
+    }
+    emit_partials<2>(acc, ws);
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_any(const T* __restrict__ a, size_t nvec, double* __restrict__ ws) {
+    double acc[1] = {0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> pa = ld<T, V>(a, i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[0] += (pa.e[e] != T(0)) ? 1.0 : 0.0;   // NaN counts, like np.any
+    }
+    emit_partials<1>(acc, ws);
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_axpby(T a, const T* __restrict__ x, T b, T* __restrict__ y, size_t nvec) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> px = ld<T, V>(x, i), py = ld<T, V>(y, i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) py.e[e] = a * px.e[e] + b * py.e[e];
+        st<T, V>(y, i, py);
+    }
+}
+
+// M(r) = r / mdiv when mdiv > 0 (pcg.py:264-267: M = x / sigmainv), identity otherwise.
+// r holds A(x0) on entry.  r = r - b ; y = M r ; p = -y ; sums: <r,y>, count(y != 0)
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_pcg_init(T* __restrict__ r, const T* __restrict__ b, T* __restrict__ p, T mdiv, size_t nvec,
+           double* __restrict__ ws) {
+    double acc[2] = {0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> pr = ld<T, V>(r, i), pb = ld<T, V>(b, i), pp;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T rr = pr.e[e] - pb.e[e];
+            const T y = mdiv > T(0) ? rr / mdiv : rr;
+            pr.e[e] = rr;
+            pp.e[e] = -y;
+            acc[0] += (double)rr * (double)y;
+            acc[1] += (y != T(0)) ? 1.0 : 0.0;
+        }
+        st<T, V>(r, i, pr);
+        st<T, V>(p, i, pp);
+    }
+    emit_partials<2>(acc, ws);
+}
+
+// x' = x + a p ; r' = r + a Ap ; y' = M r' ; sums: <r',y'>, |x'-x|^2, |x'|^2
+// alpha is read from device memory (fp64), rounded to T like the reference's scalar.
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_pcg_update(const T* __restrict__ x, const T* __restrict__ r, const T* __restrict__ p,
+             const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
+             const double* __restrict__ alpha_dev, T mdiv, size_t nvec,
+             double* __restrict__ ws) {
+    const T alpha = (T)alpha_dev[0];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> px = ld<T, V>(x, i), pr = ld<T, V>(r, i), pp = ld<T, V>(p, i),
+                   pa = ld<T, V>(Ap, i), ox, orr;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T xnew = px.e[e] + alpha * pp.e[e];
+            const T rnew = pr.e[e] + alpha * pa.e[e];
+            const T y = mdiv > T(0) ? rnew / mdiv : rnew;
+            ox.e[e] = xnew;
+            orr.e[e] = rnew;
+            const double d = (double)xnew - (double)px.e[e];
+            acc[0] += (double)rnew * (double)y;
+            acc[1] += d * d;
+            acc[2] += (double)xnew * (double)xnew;
+        }
+        st<T, V>(xn, i, ox);
+        st<T, V>(rn, i, orr);
+    }
+    emit_partials<3>(acc, ws);
+}
+
+// p = beta p - M r ; sums: count(p != 0)
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__ beta_dev,
+          T mdiv, size_t nvec, double* __restrict__ ws) {
+    const T beta = (T)beta_dev[0];
+    double acc[1] = {0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> pp = ld<T, V>(p, i), pr = ld<T, V>(r, i);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T y = mdiv > T(0) ? pr.e[e] / mdiv : pr.e[e];
+            const T v = beta * pp.e[e] - y;
+            pp.e[e] = v;
+            acc[0] += (v != T(0)) ? 1.0 : 0.0;
+        }
+        st<T, V>(p, i, pp);
+    }
+    emit_partials<1>(acc, ws);
+}
+
+// tiny scalar kernels on the device state
+__global__ void k_set_alpha(double* S) { S[S_ALPHA] = S[S_RHO] / S[S_PAP]; }
+__global__ void k_scale_alpha(double* S) { S[S_ALPHA] *= 0.75; }
+__global__ void k_set_beta(double* S) { S[S_BETA] = S[S_RHON] / S[S_RHO]; }
+__global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+static inline bool can_vec(size_t n, std::initializer_list<const void*> ptrs) {
+    if (n % V16<T>::N) return false;
+    for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ launch helpers
+#define PFB_LAUNCH_VEC(T, kern, n, ptrs, ...)                                              \
+    do {                                                                                   \
+        if (can_vec<T>(n, ptrs)) {                                                         \
+            const size_t nvec = (n) / V16<T>::N;                                           \
+            const int G = red_grid(nvec);                                                  \
+            G_used = G;                                                                    \
+            hipLaunchKernelGGL((kern<T, V16<T>::N>), dim3(G), dim3(RED_BLOCK), 0, st,      \
+                               __VA_ARGS__, nvec, ws);                                     \
+        } else {                                                                           \
+            const int G = red_grid(n);                                                     \
+            G_used = G;                                                                    \
+            hipLaunchKernelGGL((kern<T, 1>), dim3(G), dim3(RED_BLOCK), 0, st, __VA_ARGS__, \
+                               (size_t)(n), ws);                                           \
+        }                                                                                  \
+    } while (0)
+
+template <typename T>
+static int dot_impl(const void* a, const void* b, size_t n, double* out, double* ws, hipStream_t st) {
+    int G_used = 0;
+    using PL = std::initializer_list<const void*>;
+    PFB_LAUNCH_VEC(T, k_dot, n, (PL{a, b}), (const T*)a, (const T*)b);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+template <typename T>
+static int nd_impl(const void* x, const void* xp, size_t n, double* out, double* ws, hipStream_t st) {
+    int G_used = 0;
+    using PL = std::initializer_list<const void*>;
+    PFB_LAUNCH_VEC(T, k_norm_diff, n, (PL{x, xp}), (const T*)x, (const T*)xp);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 2, out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+template <typename T>
+static int any_impl(const void* a, size_t n, double* out, double* ws, hipStream_t st) {
+    int G_used = 0;
+    using PL = std::initializer_list<const void*>;
+    PFB_LAUNCH_VEC(T, k_any, n, (PL{a}), (const T*)a);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+template <typename T>
+static int axpby_impl(double a, const void* x, double b, void* y, size_t n, hipStream_t st) {
+    using PL = std::initializer_list<const void*>;
+    if (can_vec<T>(n, PL{x, y})) {
+        const size_t nvec = n / V16<T>::N;
+        hipLaunchKernelGGL((k_axpby<T, V16<T>::N>), dim3(red_grid(nvec)), dim3(RED_BLOCK), 0, st,
+                           (T)a, (const T*)x, (T)b, (T*)y, nvec);
+    } else {
+        hipLaunchKernelGGL((k_axpby<T, 1>), dim3(red_grid(n)), dim3(RED_BLOCK), 0, st,
+                           (T)a, (const T*)x, (T)b, (T*)y, n);
+    }
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+// ------------------------------------------------------------------------ PCG driver
+struct PcgWork {
+    char* r; char* p; char* Ap; char* xalt; char* ralt;
+    double* S; double* ws;
+};
+
+static size_t vec_bytes(const pfb_conv_plan* plan, int nb) {
+    const size_t esz = plan->dtype == PFB_F32 ? 4 : 8;
+    size_t b = (size_t)nb * plan->nx * plan->ny * esz;
+    return (b + 255) & ~(size_t)255;
+}
+
+template <typename T>
+static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void* x, void* r_out,
+                    const void* beam, double wsum, double sigmainv, double mdiv_d, double tol,
+                    int maxit, int minit, int backtrack, void* work, pfb_allreduce_fn allreduce,
+                    void* actx, pfb_pcg_result* res, hipStream_t st) {
+    const size_t n = (size_t)nb * plan->nx * plan->ny;
+    const size_t vb = vec_bytes(plan, nb);
+    char* w = (char*)work;
+    T* r = (T*)w;
+    T* p = (T*)(w + vb);
+    T* Ap = (T*)(w + 2 * vb);
+    T* xalt = (T*)(w + 3 * vb);
+    T* ralt = (T*)(w + 4 * vb);
+    double* S = (double*)(w + 5 * vb);
+    double* ws = S + 64;
+    const T mdiv = (T)mdiv_d;
+    double h[S_NSCALAR];
+    int G_used = 0;
+    using PL = std::initializer_list<const void*>;
+    T* xcur = (T*)x;    // current iterate lives alternately in x / xalt
+    T* rcur = r;
+    T* xnew = xalt;
+    T* rnew = ralt;
+
+    memset(res, 0, sizeof(*res));
+    PFB_HIP_CHECK(hipMemsetAsync(S, 0, sizeof(double) * 64, st));
+
+    auto reduce_hook = [&](int first, int count) -> int {
+        if (!allreduce) return PFB_OK;
+        int e2 = allreduce(actx, S + first, count, (void*)st);
+        if (e2 != 0) { set_error("pcg: allreduce hook failed (%d)", e2); return PFB_ERR_HIP; }
+        return PFB_OK;
+    };
+    auto fetch = [&]() -> int {
+        PFB_HIP_CHECK(hipMemcpyAsync(h, S, sizeof(double) * S_NSCALAR, hipMemcpyDeviceToHost, st));
+        PFB_HIP_CHECK(hipStreamSynchronize(st));
+        return PFB_OK;
+    };
+    int err;
+
+    // r = A(x0) - b ; y = M r ; p = -y                       pcg.py:71-76
+    err = pfb_psfconv_apply(plan, band0, nb, xcur, beam, wsum, sigmainv, rcur, nullptr, nullptr, (void*)st);
+    if (err != PFB_OK) return err;
+    res->matvecs = 1;
+    PFB_LAUNCH_VEC(T, k_pcg_init, n, (PL{rcur, b, p}), rcur, (const T*)b, p, mdiv);
+    hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 2, S + S_RHON);
+    // S_RHON = <r,y>, S_NUM = count(y != 0): move into place after the hook
+    if ((err = reduce_hook(S_RHON, 2)) != PFB_OK) return err;
+    hipLaunchKernelGGL(k_accept_rho, dim3(1), dim3(1), 0, st, S);
+    if ((err = fetch()) != PFB_OK) return err;
+    if (h[S_NUM] == 0.0) {                               // "Initial residual is zero"
+        res->status = PFB_PCG_ZERO_RESIDUAL;
+        res->eps = 1.0;
+        res->rnorm = h[S_RHO];
+        if (r_out) PFB_HIP_CHECK(hipMemcpyAsync(r_out, rcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        PFB_HIP_CHECK(hipStreamSynchronize(st));
+        return PFB_OK;
+    }
+
+    int k = 0;
+    double eps = 1.0;
+    double rho = h[S_RHO];
+    int status = -1;
+    while ((eps > tol || k < minit) && k < maxit) {
+        // Ap = A(p), S_PAP = <p, Ap>                      pcg.py:89-91
+        err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
+        if (err != PFB_OK) return err;
+        res->matvecs++;
+        if ((err = reduce_hook(S_PAP, 1)) != PFB_OK) return err;
+        hipLaunchKernelGGL(k_set_alpha, dim3(1), dim3(1), 0, st, S);
+        for (;;) {
+            PFB_LAUNCH_VEC(T, k_pcg_update, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
+                           (const T*)rcur, (const T*)p, (const T*)Ap, xnew, rnew,
+                           (const double*)(S + S_ALPHA), mdiv);
+            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
+            if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
+            if ((err = fetch()) != PFB_OK) return err;
+            if (backtrack && h[S_RHON] > rho) {          // pcg.py:96-101
+                hipLaunchKernelGGL(k_scale_alpha, dim3(1), dim3(1), 0, st, S);
+                res->backtracks++;
+                continue;
+            }
+            break;
+        }
+        // accept x', r'
+        { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
+        // beta = rnorm_next / rnorm ; p = beta p - y      pcg.py:103-107
+        hipLaunchKernelGGL(k_set_beta, dim3(1), dim3(1), 0, st, S);
+        PFB_LAUNCH_VEC(T, k_pcg_dir, n, (PL{p, rcur}), p, (const T*)rcur, (const double*)(S + S_BETA), mdiv);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, S + S_ANY);
+        if ((err = reduce_hook(S_ANY, 1)) != PFB_OK) return err;
+        hipLaunchKernelGGL(k_accept_rho, dim3(1), dim3(1), 0, st, S);
+        const double rho_next = h[S_RHON], num = h[S_NUM], den = h[S_DEN];
+        if ((err = fetch()) != PFB_OK) return err;
+        if (h[S_ANY] == 0.0) {                           // break BEFORE k += 1
+            status = PFB_PCG_BREAKDOWN;
+            rho = rho_next;
+            break;
+        }
+        rho = rho_next;
+        k += 1;
+        eps = sqrt(num / (1e-12 + den));                 // norm_diff, misc.py:1326-1351
+    }
+    if (status < 0) status = (k >= maxit) ? PFB_PCG_MAXIT : PFB_PCG_CONVERGED;
+    res->status = status;
+    res->iters = k;
+    res->eps = eps;
+    res->rnorm = rho;
+    if (xcur != (T*)x) PFB_HIP_CHECK(hipMemcpyAsync(x, xcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (r_out) PFB_HIP_CHECK(hipMemcpyAsync(r_out, rcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    PFB_HIP_CHECK(hipStreamSynchronize(st));
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+}  // namespace pfb
+
+using namespace pfb;
+
+extern "C" {
+
+int pfb_dot(int dtype, const void* a, const void* b, size_t n, double* out, double* ws, void* stream) {
+    PFB_REQUIRE(a && b && out && ws, PFB_ERR_INVALID, "dot: null argument");
+    return dtype == PFB_F32 ? dot_impl<float>(a, b, n, out, ws, as_stream(stream))
+                            : dot_impl<double>(a, b, n, out, ws, as_stream(stream));
+}
+
+int pfb_norm_diff_sums(int dtype, const void* x, const void* xp, size_t n, double* out, double* ws,
+                       void* stream) {
+    PFB_REQUIRE(x && xp && out && ws, PFB_ERR_INVALID, "norm_diff_sums: null argument");
+    return dtype == PFB_F32 ? nd_impl<float>(x, xp, n, out, ws, as_stream(stream))
+                            : nd_impl<double>(x, xp, n, out, ws, as_stream(stream));
+}
+
+int pfb_any_nonzero(int dtype, const void* a, size_t n, double* out, double* ws, void* stream) {
+    PFB_REQUIRE(a && out && ws, PFB_ERR_INVALID, "any_nonzero: null argument");
+    return dtype == PFB_F32 ? any_impl<float>(a, n, out, ws, as_stream(stream))
+                            : any_impl<double>(a, n, out, ws, as_stream(stream));
+}
+
+int pfb_axpby(int dtype, double a, const void* x, double b, void* y, size_t n, void* stream) {
+    PFB_REQUIRE(x && y, PFB_ERR_INVALID, "axpby: null argument");
+    return dtype == PFB_F32 ? axpby_impl<float>(a, x, b, y, n, as_stream(stream))
+                            : axpby_impl<double>(a, x, b, y, n, as_stream(stream));
+}
+
+size_t pfb_pcg_work_bytes(const pfb_conv_plan* plan, int nb) {
+    if (!plan || nb <= 0) return 0;
+    return 5 * vec_bytes(plan, nb) + sizeof(double) * (64 + PFB_REDUCE_WS_DOUBLES);
+}
+
+int pfb_pcg_solve(pfb_conv_plan* plan, int band0, int nb, const void* b, void* x, void* r_out,
+                  const void* beam, double wsum, double sigmainv, double mdiv, double tol,
+                  int maxit, int minit, int backtrack, void* work, pfb_allreduce_fn allreduce,
+                  void* allreduce_ctx, pfb_pcg_result* result, void* stream) {
+    PFB_REQUIRE(plan && b && x && work && result, PFB_ERR_INVALID, "pcg_solve: null argument");
+    PFB_REQUIRE(band0 >= 0 && nb > 0 && band0 + nb <= plan->nband, PFB_ERR_INVALID,
+                "pcg_solve: band range [%d,%d) outside plan", band0, band0 + nb);
+    PFB_REQUIRE((reinterpret_cast<uintptr_t>(work) & 255u) == 0, PFB_ERR_INVALID,
+                "pcg_solve: work must be 256-byte aligned");
+    if (plan->dtype == PFB_F32)
+        return pcg_impl<float>(plan, band0, nb, b, x, r_out, beam, wsum, sigmainv, mdiv, tol, maxit,
+                               minit, backtrack, work, allreduce, allreduce_ctx, result,
+                               as_stream(stream));
+    return pcg_impl<double>(plan, band0, nb, b, x, r_out, beam, wsum, sigmainv, mdiv, tol, maxit,
+                            minit, backtrack, work, allreduce, allreduce_ctx, result,
+                            as_stream(stream));
+}
+
+}  // extern "C"

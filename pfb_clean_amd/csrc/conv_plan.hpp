@@ -1,0 +1,34 @@
+// conv_plan.hpp -- the PSF-convolution plan shared by the generic and the pow2 kernels.
+//
+// Data layout in HBM (per band b; P = nx_psf, Q = ny_psf, M = Q/2):
+//   x, out     (nx, ny) real, row-major (caller-owned)
+//   T          half-spectrum after the row (y) transform, BLOCKED-TRANSPOSED:
+//                T[b][v / VB][i][v % VB]   v in [0, M], i in [0, nx)
+//              so a group of VB adjacent frequency columns is ONE contiguous region
+//              of nx*VB complex: the column (x) transform streams it with unit stride
+//              and the row passes write VB-wide pieces.  The column pass works in
+//              place (reads column v of T, writes column v of T).
+//   psf_l      the caller's psfhat (P, M+1) re-laid out once into the same blocking:
+//                psf_l[b][v / VB][u][v % VB]  u in [0, P)
+//   twP, twQ   exp(-2 pi i n / P), exp(-2 pi i n / Q), computed in long double.
+#pragma once
+#include "common.hpp"
+#include "fft_generic.hpp"
+
+struct pfb_conv_plan {
+    int nx, ny, P, Q, M;       // M = Q/2
+    int nband, dtype;
+    int VB, nvb;               // column blocking, number of column blocks
+    int fast;                  // 1: pow2 register-resident kernels are used
+    pfb::FftFactors frow;      // length M  (row transform on packed reals)
+    pfb::FftFactors fcol;      // length P
+    void* twP;
+    void* twQ;
+    void* psf_l;
+    void* T;
+    double* partials;          // nx * nband doubles (fused dot)
+    size_t T_elems_per_band;   // nvb * nx * VB
+    size_t psf_elems_per_band; // nvb * P * VB
+    size_t workspace_bytes;
+    int have_psf;
+};

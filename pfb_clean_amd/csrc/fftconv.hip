@@ -1,0 +1,362 @@
+// fftconv.hip -- PSF convolution plan + the coverage ("generic") kernels + C-ABI.
+//
+// out = [beam*] crop(irfft2(rfft2(pad([beam*] x)) * psfhat)) [/wsum] + sigmainv * x
+// (pfb/operators/psf.py:11-56, pfb/operators/hessian.py:129-158, 254-281)
+//
+// Three launches per apply, never materialising the zero-padded image:
+//   1. row_fwd : one image row -> packed real FFT of length Q -> M+1 bins into T
+//   2. col     : one frequency column of T -> FFT_P -> * psfhat -> IFFT_P -> first nx
+//                samples back into T (in place)
+//   3. row_inv : M+1 bins of one output row -> c2r of length Q -> crop, scale, beam,
+//                Tikhonov term, fused <dot_with, out> partial sum
+// The generic kernels here run one line per 256-thread workgroup with a runtime
+// mixed-radix Stockham FFT in LDS; fftconv_pow2.hip supplies the fast versions of the
+// same three stages on the same layouts.
+#include "conv_plan.hpp"
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+
+namespace pfb {
+
+thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// fast-path hooks (fftconv_pow2.hip)
+bool pow2_supported(const pfb_conv_plan* p);
+int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+               double scale, double sigmainv, void* out, const void* dot_with,
+               hipStream_t st);
+int pow2_prepare(pfb_conv_plan* p);
+
+struct ConvDims {
+    int nx, ny, P, Q, M, VB, nvb;
+    size_t T_band, psf_band;
+};
+
+__device__ __forceinline__ size_t t_index(const ConvDims& d, int band, int i, int v) {
+    return (size_t)band * d.T_band + ((size_t)(v / d.VB) * d.nx + i) * d.VB + (v % d.VB);
+}
+__device__ __forceinline__ size_t psf_index(const ConvDims& d, int band, int u, int v) {
+    return (size_t)band * d.psf_band + ((size_t)(v / d.VB) * d.P + u) * d.VB + (v % d.VB);
+}
+
+// ---------------------------------------------------------------- psfhat re-layout
+template <typename T>
+__global__ void k_relayout_psfhat(const cplx<T>* __restrict__ psfhat, cplx<T>* __restrict__ psf_l,
+                                  ConvDims d) {
+    // grid: (ceil(nvb*VB / 64), P, nband); thread -> v
+    const int band = blockIdx.z;
+    const int u = blockIdx.y;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.nvb * d.VB) return;
+    cplx<T> val(0, 0);
+    if (v <= d.M) val = psfhat[((size_t)band * d.P + u) * (d.M + 1) + v];
+    psf_l[psf_index(d, band, u, v)] = val;
+}
+
+// ------------------------------------------------------------------- row forward
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_row_fwd_generic(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw,
+                  const cplx<T>* __restrict__ twQ, ConvDims d, FftFactors f, int band0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* bufB = bufA + d.M;
+    const int i = blockIdx.x;
+    const int bl = blockIdx.y;                 // local band (x/beam index)
+    const int band = band0 + bl;               // plan band (T/psf index)
+    const T* xr = x + ((size_t)bl * d.nx + i) * d.ny;
+    const T* br = beam ? beam + ((size_t)bl * d.nx + i) * d.ny : nullptr;
+    // pack z[n] = x[2n] + i x[2n+1], zero beyond ny
+    for (int n = threadIdx.x; n < d.M; n += blockDim.x) {
+        const int j0 = 2 * n, j1 = 2 * n + 1;
+        T a = 0, b = 0;
+        if (j0 < d.ny) a = br ? xr[j0] * br[j0] : xr[j0];
+        if (j1 < d.ny) b = br ? xr[j1] * br[j1] : xr[j1];
+        bufA[n] = cplx<T>(a, b);
+    }
+    cplx<T>* Z = fft_lds_generic<T, false>(bufA, bufB, f, twQ, 2);
+    // X[v] = 1/2 [ (Z[v] + conj Z[M-v]) - i w_Q^v (Z[v] - conj Z[M-v]) ],  v = 0..M
+    for (int v = threadIdx.x; v <= d.M; v += blockDim.x) {
+        const cplx<T> zv = Z[v == d.M ? 0 : v];
+        const cplx<T> zm = conj(Z[v == 0 ? 0 : d.M - v]);
+        const cplx<T> w = twQ[v];
+        const cplx<T> s = zv + zm;
+        const cplx<T> t = mul_mi(w * (zv - zm));
+        Tw[t_index(d, band, i, v)] = T(0.5) * (s + t);
+    }
+}
+
+// ------------------------------------------------------------------------ column
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_col_generic(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
+              const cplx<T>* __restrict__ twP, ConvDims d, FftFactors f, int band0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* bufB = bufA + d.P;
+    const int v = blockIdx.x;
+    const int band = band0 + blockIdx.y;
+    for (int n = threadIdx.x; n < d.P; n += blockDim.x)
+        bufA[n] = n < d.nx ? Tw[t_index(d, band, n, v)] : cplx<T>(0, 0);
+    cplx<T>* X = fft_lds_generic<T, false>(bufA, bufB, f, twP, 1);
+    for (int u = threadIdx.x; u < d.P; u += blockDim.x)
+        X[u] = X[u] * psf_l[psf_index(d, band, u, v)];
+    cplx<T>* other = (X == bufA) ? bufB : bufA;
+    cplx<T>* Y = fft_lds_generic<T, true>(X, other, f, twP, 1);
+    for (int n = threadIdx.x; n < d.nx; n += blockDim.x)
+        Tw[t_index(d, band, n, v)] = Y[n];
+}
+
+// ------------------------------------------------------------------- row inverse
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_row_inv_generic(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
+                  const T* __restrict__ x, const T* __restrict__ beam,
+                  const T* __restrict__ dot_with, T* __restrict__ out,
+                  double* __restrict__ partials, ConvDims d, FftFactors f, int band0,
+                  T scale, T sigmainv) {
+    // all LDS in the one dynamic array (a static __shared__ beside it would eat into
+    // the 160 KB limit and shift the 16-byte alignment of the dynamic base)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);              // 64 B
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem + 64);
+    cplx<T>* bufB = bufA + d.M;
+    const int i = blockIdx.x;
+    const int bl = blockIdx.y;
+    const int band = band0 + bl;
+    // Z[v] = (Y[v] + conj Y[M-v]) + i conj(w_Q^v) (Y[v] - conj Y[M-v]),  v < M
+    // imaginary parts of the DC and Nyquist bins are ignored (ducc0/pocketfft c2r)
+    for (int v = threadIdx.x; v < d.M; v += blockDim.x) {
+        cplx<T> yv = Tw[t_index(d, band, i, v)];
+        cplx<T> ym = Tw[t_index(d, band, i, d.M - v)];
+        if (v == 0) { yv.y = 0; ym.y = 0; }
+        ym = conj(ym);
+        const cplx<T> w = twQ[v];
+        bufA[v] = (yv + ym) + mul_i(mulc(yv - ym, w));
+    }
+    cplx<T>* z = fft_lds_generic<T, true>(bufA, bufB, f, twQ, 2);
+    const size_t rowoff = ((size_t)bl * d.nx + i) * d.ny;
+    double acc[1] = {0.0};
+    for (int j = threadIdx.x; j < d.ny; j += blockDim.x) {
+        const cplx<T> zz = z[j >> 1];
+        T val = ((j & 1) ? zz.y : zz.x) * scale;
+        if (beam) val *= beam[rowoff + j];
+        val += sigmainv * x[rowoff + j];
+        out[rowoff + j] = val;
+        if (dot_with) acc[0] += (double)dot_with[rowoff + j] * (double)val;
+    }
+    if (dot_with) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) partials[(size_t)bl * d.nx + i] = acc[0];
+    }
+}
+
+// sum `n` partials in a fixed order into out[0]
+__global__ void __launch_bounds__(256)
+k_sum_partials(const double* __restrict__ partials, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    double acc[1] = {0.0};
+    // fixed assignment of elements to threads and fixed tree => deterministic
+    for (int k = threadIdx.x; k < n; k += blockDim.x) acc[0] += partials[k];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+static ConvDims dims_of(const pfb_conv_plan* p) {
+    ConvDims d;
+    d.nx = p->nx; d.ny = p->ny; d.P = p->P; d.Q = p->Q; d.M = p->M;
+    d.VB = p->VB; d.nvb = p->nvb;
+    d.T_band = p->T_elems_per_band; d.psf_band = p->psf_elems_per_band;
+    return d;
+}
+
+template <typename T>
+static int upload_twiddles(int n, void** dev) {
+    std::vector<cplx<T>> h(n);
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < n; ++k) {
+        // octant-exact: reduce the angle so that sin/cos see |a| <= pi/4 where possible
+        long double a = two_pi * (long double)k / (long double)n;
+        h[k].x = (T)cosl(a);
+        h[k].y = (T)(-sinl(a));
+    }
+    PFB_HIP_CHECK(hipMalloc(dev, sizeof(cplx<T>) * (size_t)n));
+    PFB_HIP_CHECK(hipMemcpy(*dev, h.data(), sizeof(cplx<T>) * (size_t)n, hipMemcpyHostToDevice));
+    return PFB_OK;
+}
+
+template <typename T>
+static int apply_generic(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                         double scale, double sigmainv, void* out, const void* dot_with,
+                         hipStream_t st) {
+    const ConvDims d = dims_of(p);
+    const size_t lds_row = 64 + 2 * sizeof(cplx<T>) * (size_t)p->M;
+    const size_t lds_col = 2 * sizeof(cplx<T>) * (size_t)p->P;
+    hipLaunchKernelGGL((k_row_fwd_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
+                       (const T*)x, (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)p->twQ,
+                       d, p->frow, band0);
+    hipLaunchKernelGGL((k_col_generic<T>), dim3(p->M + 1, nb), dim3(256), lds_col, st,
+                       (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
+                       d, p->fcol, band0);
+    hipLaunchKernelGGL((k_row_inv_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
+                       (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const T*)x,
+                       (const T*)beam, (const T*)dot_with, (T*)out, p->partials, d, p->frow,
+                       band0, (T)scale, (T)sigmainv);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+template <typename T>
+static int set_lds_limits(const pfb_conv_plan*) {
+    // the attribute is per function, not per launch: always raise it to the whole
+    // 160 KB of a gfx950 CU so plans of different sizes can coexist
+    const int lds_max = 160 * 1024;
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_generic<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_generic<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_generic<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    return PFB_OK;
+}
+
+}  // namespace pfb
+
+using namespace pfb;
+
+extern "C" {
+
+int pfb_abi_version(void) { return PFB_ABI_VERSION; }
+const char* pfb_last_error(void) { return pfb::g_err; }
+
+int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, int dtype,
+                            pfb_conv_plan** plan) {
+    PFB_REQUIRE(plan != nullptr, PFB_ERR_INVALID, "plan_create: null plan pointer");
+    *plan = nullptr;
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "plan_create: bad dtype %d", dtype);
+    PFB_REQUIRE(nx > 0 && ny > 0 && nband > 0, PFB_ERR_INVALID, "plan_create: non-positive size");
+    PFB_REQUIRE(nx <= nx_psf && ny <= ny_psf, PFB_ERR_INVALID,
+                "plan_create: image (%d,%d) larger than psf grid (%d,%d)", nx, ny, nx_psf, ny_psf);
+    PFB_REQUIRE(ny_psf % 2 == 0, PFB_ERR_UNSUPPORTED,
+                "plan_create: ny_psf=%d must be even (pfb's grid worker makes it so)", ny_psf);
+    PFB_REQUIRE(factorable(nx_psf) && factorable(ny_psf / 2), PFB_ERR_UNSUPPORTED,
+                "plan_create: (%d,%d) has a prime factor > 13", nx_psf, ny_psf);
+    pfb_conv_plan* p = (pfb_conv_plan*)calloc(1, sizeof(pfb_conv_plan));
+    PFB_REQUIRE(p != nullptr, PFB_ERR_ALLOC, "plan_create: host alloc failed");
+    p->nx = nx; p->ny = ny; p->P = nx_psf; p->Q = ny_psf; p->M = ny_psf / 2;
+    p->nband = nband; p->dtype = dtype;
+    const size_t csz = dtype == PFB_F32 ? 8 : 16;
+    p->fast = pow2_supported(p) ? 1 : 0;
+    if (const char* e = getenv("PFB_FORCE_GENERIC")) { if (atoi(e)) p->fast = 0; }
+    int vb = p->fast ? 2 : 1;
+    if (const char* e = getenv("PFB_VB")) { int t = atoi(e); if (t >= 1 && t <= 16) vb = t; }
+    p->VB = vb;
+    p->nvb = (p->M + 1 + vb - 1) / vb;
+    p->T_elems_per_band = (size_t)p->nvb * nx * vb;
+    p->psf_elems_per_band = (size_t)p->nvb * p->P * vb;
+    if (!plan_factors(p->M, &p->frow) || !plan_factors(p->P, &p->fcol)) {
+        free(p);
+        set_error("plan_create: cannot factor (%d,%d)", nx_psf, ny_psf / 2);
+        return PFB_ERR_UNSUPPORTED;
+    }
+    if (!p->fast) {
+        const size_t lds_need = 64 + 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
+        if (lds_need > 160 * 1024) {
+            free(p);
+            set_error("plan_create: generic path needs %zu B of LDS (> 160 KB) for grid (%d,%d); "
+                      "use a power-of-two grid with nx_psf = 2 nx", lds_need, nx_psf, ny_psf);
+            return PFB_ERR_UNSUPPORTED;
+        }
+    }
+    int rc = (dtype == PFB_F32) ? upload_twiddles<float>(p->P, &p->twP) : upload_twiddles<double>(p->P, &p->twP);
+    if (rc == PFB_OK)
+        rc = (dtype == PFB_F32) ? upload_twiddles<float>(p->Q, &p->twQ) : upload_twiddles<double>(p->Q, &p->twQ);
+    const size_t tbytes = csz * p->T_elems_per_band * nband;
+    const size_t pbytes = csz * p->psf_elems_per_band * nband;
+    if (rc == PFB_OK && hipMalloc(&p->T, tbytes) != hipSuccess) rc = PFB_ERR_ALLOC;
+    if (rc == PFB_OK && hipMalloc(&p->psf_l, pbytes) != hipSuccess) rc = PFB_ERR_ALLOC;
+    if (rc == PFB_OK && hipMalloc((void**)&p->partials, sizeof(double) * (size_t)nx * nband) != hipSuccess)
+        rc = PFB_ERR_ALLOC;
+    if (rc == PFB_OK) {
+        p->workspace_bytes = tbytes + pbytes;
+        rc = (dtype == PFB_F32) ? set_lds_limits<float>(p) : set_lds_limits<double>(p);
+        if (p->fast && rc == PFB_OK) rc = pow2_prepare(p);
+    }
+    if (rc != PFB_OK) {
+        if (rc == PFB_ERR_ALLOC) set_error("plan_create: device allocation failed (%zu B)", tbytes + pbytes);
+        pfb_psfconv_plan_destroy(p);
+        return rc;
+    }
+    *plan = p;
+    return PFB_OK;
+}
+
+int pfb_psfconv_plan_destroy(pfb_conv_plan* p) {
+    if (!p) return PFB_OK;
+    if (p->twP) (void)hipFree(p->twP);
+    if (p->twQ) (void)hipFree(p->twQ);
+    if (p->psf_l) (void)hipFree(p->psf_l);
+    if (p->T) (void)hipFree(p->T);
+    if (p->partials) (void)hipFree(p->partials);
+    free(p);
+    return PFB_OK;
+}
+
+int pfb_psfconv_plan_info(const pfb_conv_plan* p, int* fast_path, int* vb, size_t* workspace_bytes) {
+    PFB_REQUIRE(p != nullptr, PFB_ERR_INVALID, "plan_info: null plan");
+    if (fast_path) *fast_path = p->fast;
+    if (vb) *vb = p->VB;
+    if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
+    return PFB_OK;
+}
+
+int pfb_psfconv_set_psfhat(pfb_conv_plan* p, const void* psfhat, void* stream) {
+    PFB_REQUIRE(p && psfhat, PFB_ERR_INVALID, "set_psfhat: null argument");
+    const ConvDims d = dims_of(p);
+    dim3 grid((p->nvb * p->VB + 63) / 64, p->P, p->nband);
+    if (p->dtype == PFB_F32)
+        hipLaunchKernelGGL((k_relayout_psfhat<float>), grid, dim3(64), 0, as_stream(stream),
+                           (const cplx<float>*)psfhat, (cplx<float>*)p->psf_l, d);
+    else
+        hipLaunchKernelGGL((k_relayout_psfhat<double>), grid, dim3(64), 0, as_stream(stream),
+                           (const cplx<double>*)psfhat, (cplx<double>*)p->psf_l, d);
+    PFB_HIP_CHECK(hipGetLastError());
+    p->have_psf = 1;
+    return PFB_OK;
+}
+
+int pfb_psfconv_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                      double wsum, double sigmainv, void* out, const void* dot_with,
+                      double* dot_out, void* stream) {
+    PFB_REQUIRE(p && x && out, PFB_ERR_INVALID, "apply: null argument");
+    PFB_REQUIRE(p->have_psf, PFB_ERR_INVALID, "apply: pfb_psfconv_set_psfhat was never called");
+    PFB_REQUIRE(band0 >= 0 && nb > 0 && band0 + nb <= p->nband, PFB_ERR_INVALID,
+                "apply: band range [%d,%d) outside plan (nband=%d)", band0, band0 + nb, p->nband);
+    PFB_REQUIRE(x != out, PFB_ERR_INVALID, "apply: out must not alias x");
+    PFB_REQUIRE(!dot_with || dot_out, PFB_ERR_INVALID, "apply: dot_with given without dot_out");
+    hipStream_t st = as_stream(stream);
+    double scale = 1.0 / ((double)p->P * (double)p->Q);
+    if (wsum > 0) scale /= wsum;
+    int rc;
+    if (p->fast)
+        rc = pow2_apply(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+    else if (p->dtype == PFB_F32)
+        rc = apply_generic<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+    else
+        rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+    if (rc != PFB_OK) return rc;
+    if (dot_with) {
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials, p->nx * nb, dot_out);
+        PFB_HIP_CHECK(hipGetLastError());
+    }
+    return PFB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""
+PSF convolution on MI355X -- drop-in for pfb/operators/psf.py:11-56.
+
+    psf_convolve_slice(xpad, xhat, xout, psfhat, lastsize, x, nthreads=1)
+    psf_convolve_cube (xpad, xhat, xout, psfhat, lastsize, x, nthreads=1)
+
+Same positional order and aliasing contract as the reference: the result is written
+into and returned as `xout` (psf.py:29,56) and `x` is not overwritten.  `xpad`/`xhat`
+are the reference's host scratch buffers; the HIP path never materialises the padded
+image or its spectrum, so they are accepted and ignored (None is fine).  numpy
+arguments are staged through the GPU (PCIe both ways per call); torch-ROCm tensors
+stay resident -- that is the fast way to drive it.
+
+The psfhat re-layout happens once per distinct psfhat (plan cache keyed on the
+buffer identity + a strided fingerprint), mirroring how the workers bind psfhat once
+with functools.partial (workers/spotless.py:175-183).
+"""
+import ctypes as C
+import threading
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .. import _lib, _dev
+
+
+class PsfConvPlan:
+    """Owns the device plan (twiddles, re-laid-out psfhat, spectrum workspace) for one
+    psfhat cube.  psfhat: (nband, nx_psf, nyo2) or (nx_psf, nyo2) complex."""
+
+    def __init__(self, psfhat, nx, ny, lastsize):
+        lib = _lib.load()
+        ph = _dev.to_dev(psfhat)
+        if ph.dtype not in _dev.REAL_OF:
+            raise TypeError(f"psfhat must be complex64/complex128, got {ph.dtype}")
+        if ph.ndim == 2:
+            ph = ph[None]
+        if ph.ndim != 3:
+            raise ValueError("psfhat must be (nx_psf, nyo2) or (nband, nx_psf, nyo2)")
+        self.nband, self.nx_psf, self.nyo2 = ph.shape
+        self.nx, self.ny, self.lastsize = int(nx), int(ny), int(lastsize)
+        if self.nyo2 != self.lastsize // 2 + 1:
+            raise ValueError(f"psfhat last axis {self.nyo2} != lastsize//2+1 "
+                             f"({self.lastsize // 2 + 1})")
+        self.rdtype = _dev.REAL_OF[ph.dtype]
+        self.code = _dev.code(self.rdtype)
+        self.device = ph.device
+        h = C.c_void_p()
+        _lib.check(lib.pfb_psfconv_plan_create(self.nx, self.ny, self.nx_psf, self.lastsize,
+                                               self.nband, self.code, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        _lib.check(lib.pfb_psfconv_set_psfhat(h, _dev.ptr(ph.contiguous()), _dev.stream()))
+        torch.cuda.current_stream().synchronize()      # ph may be a temporary
+        fast, vb, wsb = C.c_int(), C.c_int(), C.c_size_t()
+        lib.pfb_psfconv_plan_info(h, C.byref(fast), C.byref(vb), C.byref(wsb))
+        self.fast_path, self.vb, self.workspace_bytes = bool(fast.value), vb.value, wsb.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def apply(self, x, out=None, beam=None, wsum=None, sigmainv=0.0, band0=0,
+              dot_with=None, dot_out=None):
+        """out = [beam*]conv([beam*]x)[/wsum] + sigmainv*x on bands
+        [band0, band0+nb) where nb = x.shape[0] (x is (nb, nx, ny) or (nx, ny))."""
+        squeeze = x.ndim == 2
+        x3 = x[None] if squeeze else x
+        if x3.dtype != self.rdtype or not x3.is_cuda:
+            raise TypeError(f"x must be a {self.rdtype} GPU tensor, got {x3.dtype}")
+        nb = x3.shape[0]
+        if tuple(x3.shape[1:]) != (self.nx, self.ny):
+            raise ValueError(f"x has shape {tuple(x.shape)}, plan is for ({self.nx},{self.ny})")
+        x3 = x3.contiguous()
+        if out is None:
+            out3 = torch.empty_like(x3)
+        else:
+            out3 = out[None] if out.ndim == 2 else out
+            if not out3.is_contiguous() or out3.dtype != self.rdtype or out3.shape != x3.shape:
+                raise ValueError("out must be a contiguous tensor shaped like x")
+        if beam is not None:
+            beam = beam[None] if beam.ndim == 2 else beam
+            if beam.shape != x3.shape:
+                raise ValueError('Beam has incorrect shape')
+            beam = beam.contiguous()
+        if dot_with is not None:
+            dot_with = dot_with.contiguous()
+        _lib.check(self._lib.pfb_psfconv_apply(
+            self._h, int(band0), int(nb), _dev.ptr(x3), _dev.ptr(beam),
+            float(wsum) if wsum is not None else 0.0, float(sigmainv), _dev.ptr(out3),
+            _dev.ptr(dot_with), _dev.ptr(dot_out), _dev.stream()))
+        return out3[0] if squeeze else out3
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            torch.cuda.synchronize()
+            self._lib.pfb_psfconv_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------- plan cache
+_cache = OrderedDict()
+_cache_lock = threading.Lock()
+_CACHE_MAX = 8
+
+
+def _fingerprint(psfhat):
+    if isinstance(psfhat, np.ndarray):
+        flat = psfhat.reshape(-1)
+        step = max(1, flat.size // 257)
+        samp = flat[::step][:257]
+        return ('np', psfhat.__array_interface__['data'][0], psfhat.shape, str(psfhat.dtype),
+                complex(samp.sum()))
+    return ('t', psfhat.data_ptr(), tuple(psfhat.shape), str(psfhat.dtype), psfhat._version,
+            str(psfhat.device))
+
+
+def plan_for(psfhat, nx, ny, lastsize):
+    key = (_fingerprint(psfhat), int(nx), int(ny), int(lastsize))
+    with _cache_lock:
+        plan = _cache.get(key)
+        if plan is not None:
+            _cache.move_to_end(key)
+            return plan
+    plan = PsfConvPlan(psfhat, nx, ny, lastsize)
+    with _cache_lock:
+        _cache[key] = plan
+        while len(_cache) > _CACHE_MAX:
+            _cache.popitem(last=False)
+    return plan
+
+
+def clear_plan_cache():
+    with _cache_lock:
+        _cache.clear()
+
+
+# ---------------------------------------------------------------- reference API
+def _run(psfhat, lastsize, x, xout, beam=None, wsum=None, sigmainv=0.0):
+    xd = _dev.to_dev(x)
+    nx, ny = xd.shape[-2:]
+    plan = plan_for(psfhat, nx, ny, lastsize)
+    if xd.dtype != plan.rdtype:
+        raise TypeError(f"x is {xd.dtype} but psfhat is {psfhat.dtype}")
+    bd = _dev.to_dev(beam, plan.rdtype) if beam is not None else None
+    direct = isinstance(xout, torch.Tensor) and xout.is_cuda and xout.is_contiguous() \
+        and xout.dtype == plan.rdtype and tuple(xout.shape) == tuple(xd.shape) \
+        and xout.data_ptr() != xd.data_ptr()
+    res = plan.apply(xd, out=xout if direct else None, beam=bd, wsum=wsum, sigmainv=sigmainv)
+    if direct:
+        return xout
+    if xout is None:
+        return res.cpu().numpy() if _dev.is_numpy(x) else res
+    if _dev.is_numpy(xout):
+        xout[...] = res.cpu().numpy()
+    else:
+        xout.copy_(res)
+    return xout
+
+
+def psf_convolve_slice(xpad, xhat, xout, psfhat, lastsize, x, nthreads=1):
+    """pfb/operators/psf.py:11-29.  x (nx, ny), psfhat (nx_psf, nyo2)."""
+    if x.ndim != 2 or psfhat.ndim != 2:
+        raise ValueError("psf_convolve_slice expects 2-D x and psfhat")
+    return _run(psfhat, lastsize, x, xout)
+
+
+def psf_convolve_cube(xpad, xhat, xout, psfhat, lastsize, x, nthreads=1):
+    """pfb/operators/psf.py:32-56.  x (nband, nx, ny), psfhat (nband, nx_psf, nyo2)."""
+    if x.ndim != 3 or psfhat.ndim != 3:
+        raise ValueError("psf_convolve_cube expects 3-D x and psfhat")
+    if x.shape[0] != psfhat.shape[0]:
+        raise ValueError("x and psfhat disagree on the number of bands")
+    return _run(psfhat, lastsize, x, xout)

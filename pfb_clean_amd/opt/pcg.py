@@ -1,0 +1,283 @@
+"""
+Preconditioned conjugate gradients on MI355X -- drop-in for pfb/opt/pcg.py.
+
+    pcg(A, b, x0=None, M=None, tol=1e-5, maxit=500, minit=100, verbosity=1,
+        report_freq=10, backtrack=True, return_resid=False)          pcg.py:53-136
+    pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, sigmainv, cgopts, compute=True)
+                                                                      pcg.py:243-360
+
+Two execution paths with identical semantics (residual r = A x - b, stopping rule
+`(eps > tol or k < minit) and k < maxit`, backtracking without extra matvecs,
+break-before-increment on an all-zero direction, "Initial residual is zero" returns x0):
+
+ * FUSED: when `A` is a HessianPsf (or a functools.partial of this package's
+   hessian_psf_cube / _hessian_psf_slice, which is exactly what the reference workers
+   build -- fluxmop.py:160-174, pcg.py:276-284) and `M` is None or a DivPrecond, the
+   whole solve runs inside libpfb_hip.so (pfb_pcg_solve): 3 convolution kernels + 3
+   fused vector kernels per iteration, device-resident scalars.
+ * GENERIC: any Python callables A, M.  Vector arithmetic and reductions still run in
+   the HIP kernels (pfb_dot, pfb_axpby, pfb_norm_diff_sums, pfb_any_nonzero); A and M
+   are called with the same array kind (numpy / tensor) the caller passed for `b`.
+"""
+import ctypes as C
+import functools
+import math
+import sys
+
+import numpy as np
+import torch
+
+from .. import _lib, _dev
+from ..operators import hessian as _hess
+from ..operators.hessian import HessianPsf
+
+
+class DivPrecond:
+    """M(x) = x / div -- the diagonal preconditioner of pcg.py:264-267."""
+
+    def __init__(self, div):
+        self.div = float(div)
+
+    def __call__(self, x):
+        return x / self.div
+
+
+def _log(msg, verbosity, level=1):
+    if verbosity >= level:
+        print(msg, file=sys.stderr)
+
+
+def _as_hessian(A, b):
+    """Recognise the operator objects / partials the fused driver can run."""
+    if isinstance(A, HessianPsf):
+        return A
+    if isinstance(A, functools.partial) and not A.keywords.get('_nofuse', False):
+        kw = dict(A.keywords)
+        args = A.args
+        nx, ny = b.shape[-2:]
+        try:
+            if A.func is _hess.hessian_psf_cube and len(args) == 6:
+                _, _, _, beam, psfhat, lastsize = args
+            elif A.func is _hess._hessian_psf_slice and len(args) == 6:
+                _, _, _, psfhat, beam, lastsize = args
+            else:
+                return None
+        except ValueError:
+            return None
+        return HessianPsf(psfhat, nx, ny, lastsize, beam=beam,
+                          sigmainv=kw.get('sigmainv', 1), wsum=kw.get('wsum', None))
+    return None
+
+
+class _Work:
+    """Device scratch for pfb_pcg_solve, cached per (plan, nb)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, plan, nb):
+        key = (id(plan), nb, _dev.stream())
+        w = cls._cache.get(key)
+        if w is None:
+            nbytes = _lib.load().pfb_pcg_work_bytes(plan.handle, nb)
+            if len(cls._cache) > 4:
+                cls._cache.clear()
+            w = cls._cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
+        return w
+
+
+def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack=True,
+              return_resid=False, allreduce=None):
+    """Run pfb_pcg_solve.  b, x0: GPU tensors (nb, nx, ny) | (nx, ny).  Returns
+    (x, r|None, PcgResult).  allreduce: optional callable(tensor_view_of_doubles) that
+    sums in place over ranks (see pfb_clean_amd.dist)."""
+    lib = _lib.load()
+    plan = A.plan
+    squeeze = b.ndim == 2
+    b3 = (b[None] if squeeze else b).contiguous()
+    nb = b3.shape[0]
+    if nb != A.nb:
+        raise ValueError(f"b has {nb} bands, operator has {A.nb}")
+    if b3.dtype != plan.rdtype:
+        raise TypeError(f"b is {b3.dtype}, operator is {plan.rdtype}")
+    x = torch.zeros_like(b3) if x0 is None else (x0[None] if squeeze else x0).contiguous().clone()
+    r = torch.empty_like(b3) if return_resid else None
+    work = _Work.get(plan, nb)
+    res = _lib.PcgResult()
+    if allreduce is None:
+        cb = _lib.ALLREDUCE_FN(0)
+    else:
+        def _hook(ctx, buf, count, stream):
+            try:
+                allreduce(buf, count)
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                print(f"pfb_clean_amd: allreduce hook failed: {e!r}", file=sys.stderr)
+                return 1
+        cb = _lib.ALLREDUCE_FN(_hook)
+    _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
+                                 _dev.ptr(A.beam), A.wsum if A.wsum is not None else 0.0,
+                                 A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
+                                 int(bool(backtrack)), _dev.ptr(work), cb, None, C.byref(res),
+                                 _dev.stream()))
+    if squeeze:
+        x = x[0]
+        r = None if r is None else r[0]
+    return x, r, res
+
+
+def _report(res_status, k, eps, verbosity):
+    if res_status == 'maxit':
+        _log(f"Max iters reached. eps = {eps:.3e}", verbosity)
+    elif res_status in ('converged', 'breakdown'):
+        _log(f"Success, converged after {k} iterations", verbosity)
+
+
+def pcg(A, b, x0=None, M=None, tol=1e-5, maxit=500, minit=100, verbosity=1,
+        report_freq=10, backtrack=True, return_resid=False):
+    """pfb/opt/pcg.py:53-136."""
+    H = _as_hessian(A, b)
+    fusable_M = M is None or isinstance(M, DivPrecond)
+    as_numpy = _dev.is_numpy(b)
+    if H is not None and fusable_M:
+        bd = _dev.to_dev(b)
+        x0d = None if x0 is None else _dev.to_dev(x0, bd.dtype)
+        x, r, res = pcg_fused(H, bd, x0d, mdiv=M.div if M is not None else 0.0, tol=tol,
+                              maxit=maxit, minit=minit, backtrack=backtrack,
+                              return_resid=return_resid)
+        status = _lib.PCG_STATUS[res.status]
+        if status == 'zero-residual':
+            _log("Initial residual is zero", verbosity)
+            # the reference returns x0 itself, and ONLY x0, even with return_resid
+            return x0 if x0 is not None else (x.cpu().numpy() if as_numpy else x)
+        _report(status, res.iters, res.eps, verbosity)
+        if as_numpy:
+            x = x.cpu().numpy()
+            r = None if r is None else r.cpu().numpy()
+        return (x, r) if return_resid else x
+    return _pcg_generic(A, b, x0, M, tol, maxit, minit, verbosity, report_freq, backtrack,
+                        return_resid)
+
+
+def _pcg_generic(A, b, x0, M, tol, maxit, minit, verbosity, report_freq, backtrack,
+                 return_resid):
+    lib = _lib.load()
+    as_numpy = _dev.is_numpy(b)
+    bd = _dev.to_dev(b).contiguous()
+    dt = bd.dtype
+    code = _dev.code(dt)
+    n = bd.numel()
+    st = _dev.stream
+    ws, out = _dev.scratch()
+
+    def host(t):
+        return t.cpu().numpy() if as_numpy else t
+
+    def dev(a):
+        return _dev.to_dev(a, dt).contiguous()
+
+    def callA(v):
+        return dev(A(host(v))).clone() if not as_numpy else dev(A(host(v)))
+
+    def callM(v):
+        return v if M is None else dev(M(host(v)))
+
+    def dot(u, v):
+        _lib.check(lib.pfb_dot(code, _dev.ptr(u), _dev.ptr(v), n, _dev.ptr(out), _dev.ptr(ws), st()))
+        return out[0].item()
+
+    def anynz(u):
+        _lib.check(lib.pfb_any_nonzero(code, _dev.ptr(u), n, _dev.ptr(out), _dev.ptr(ws), st()))
+        return out[0].item() != 0.0
+
+    def axpby(a, u, bb, v):       # v = a*u + bb*v
+        _lib.check(lib.pfb_axpby(code, float(a), _dev.ptr(u), float(bb), _dev.ptr(v), n, st()))
+
+    x0_in = x0
+    x = torch.zeros_like(bd) if x0 is None else dev(x0).clone()
+    r = callA(x)
+    axpby(-1.0, bd, 1.0, r)                          # r = A(x0) - b
+    y = callM(r)
+    if not anynz(y):
+        _log("Initial residual is zero", verbosity)
+        return x0_in if x0_in is not None else host(x)
+    p = y.clone()
+    axpby(0.0, y, -1.0, p)                           # p = -y
+    k = 0
+    eps = 1.0
+    xp = torch.empty_like(x)
+    rp = torch.empty_like(r)
+    broke = False
+    while (eps > tol or k < minit) and k < maxit:
+        xp.copy_(x)
+        rp.copy_(r)
+        Ap = callA(p)
+        rnorm = dot(r, y)
+        alpha = rnorm / dot(p, Ap)
+        x.copy_(xp); axpby(alpha, p, 1.0, x)
+        r.copy_(rp); axpby(alpha, Ap, 1.0, r)
+        y = callM(r)
+        rnorm_next = dot(r, y)
+        while rnorm_next > rnorm and backtrack:
+            alpha *= 0.75
+            x.copy_(xp); axpby(alpha, p, 1.0, x)
+            r.copy_(rp); axpby(alpha, Ap, 1.0, r)
+            y = callM(r)
+            rnorm_next = dot(r, y)
+        beta = rnorm_next / rnorm
+        axpby(-1.0, y, beta, p)                      # p = beta*p - y
+        if not anynz(p):
+            broke = True
+            break
+        k += 1
+        _lib.check(lib.pfb_norm_diff_sums(code, _dev.ptr(x), _dev.ptr(xp), n, _dev.ptr(out),
+                                          _dev.ptr(ws), st()))
+        num, den = out[:2].tolist()
+        eps = math.sqrt(num / (1e-12 + den))
+        if not k % report_freq and verbosity > 1:
+            _log(f"At iteration {k} epsx = {eps:.3e}", verbosity, 2)
+    _report('maxit' if (k >= maxit and not broke) else 'converged', k, eps, verbosity)
+    if not return_resid:
+        return host(x)
+    return host(x), host(r)
+
+
+def pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, sigmainv, cgopts, compute=True):
+    """pfb/opt/pcg.py:310-360 (+ _pcg_psf_impl :243-291): independent PCG per band with
+    A = _hessian_psf_slice(psfhat[k], beam[k], sigmainv) and M = x/sigmainv when
+    sigmainv > 0.  The reference's dask blockwise-over-bands becomes a loop of fused
+    device solves on one plan (bands are independent: shard them over GPUs with
+    pfb_clean_amd.dist.shard_bands for multi-GPU)."""
+    as_numpy = _dev.is_numpy(b)
+    bd = _dev.to_dev(b)
+    nband, nx, ny = bd.shape
+    if psfhat.shape[0] != nband:
+        raise ValueError("psfhat and b disagree on the number of bands")
+    beamd = None
+    if beam is not None:
+        beamd = _dev.to_dev(beam, bd.dtype)
+        if beamd.ndim == 2:
+            beamd = beamd[None]
+        if beamd.shape[0] == 1:
+            beamd = beamd.expand(nband, -1, -1)
+        elif beamd.shape[0] != nband:
+            raise ValueError('Beam has incorrect shape')
+    x0d = torch.zeros_like(bd) if x0 is None else _dev.to_dev(x0, bd.dtype)
+    from ..operators.psf import plan_for
+    plan = plan_for(psfhat, nx, ny, lastsize)
+    model = torch.zeros_like(bd)
+    opts = dict(cgopts)
+    verbosity = opts.pop('verbosity', 1)
+    opts.pop('report_freq', None)
+    mdiv = sigmainv if sigmainv > 0 else 0.0
+    for k in range(nband):
+        A = HessianPsf(plan, nx, ny, lastsize, beam=None if beamd is None else beamd[k:k + 1],
+                       sigmainv=sigmainv, band0=k, nb=1)
+        x, _, res = pcg_fused(A, bd[k:k + 1], x0d[k:k + 1], mdiv=mdiv, **opts)
+        status = _lib.PCG_STATUS[res.status]
+        if status == 'zero-residual':
+            _log("Initial residual is zero", verbosity)
+            model[k] = x0d[k]
+        else:
+            _report(status, res.iters, res.eps, verbosity)
+            model[k] = x[0]
+    return model.cpu().numpy() if as_numpy else model

@@ -1,0 +1,288 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the
+C-ABI library via the reference-shaped Python entry points, against
+
+  * the golden vectors the reference's own source produced (tests/golden/*.npz), and
+  * the CPU oracle (oracle/) on seeded inputs.
+
+Tolerances: fp64 conv 1e-12, fp64 PCG iterate 1e-9; fp32 conv 1e-5,
+fp32 PCG iterate 1e-3 -- all relative to max|reference|.
+"""
+from functools import partial
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import fftconv as ofc          # noqa: E402  (checker only)
+from oracle import solvers as osv          # noqa: E402
+
+pmp = pytest.mark.parametrize
+
+TOL_CONV = {np.float64: 1e-12, np.float32: 1e-5}
+TOL_PCG = {np.float64: 1e-9, np.float32: 1e-3}
+
+
+@pytest.fixture(scope='module')
+def amd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators import psf, hessian
+    from pfb_clean_amd.opt import pcg as pcgmod, power_method as pmmod
+    from pfb_clean_amd.utils import misc
+
+    class NS:
+        pass
+    ns = NS()
+    ns.psf, ns.hessian, ns.pcg, ns.pm, ns.misc = psf, hessian, pcgmod, pmmod, misc
+    return ns
+
+
+def relerr(a, ref):
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-300)
+
+
+def cdt(rdt):
+    return np.complex64 if rdt == np.float32 else np.complex128
+
+
+# ----------------------------------------------------------------------- conv
+@pmp('rdt', [np.float64, np.float32])
+@pmp('c', range(6))
+def test_conv_and_hessian_golden(amd, golden, c, rdt):
+    g = golden('conv')
+    nx, ny, P, Q = (int(v) for v in g['cases'][c])
+    psfhat = g[f'c{c}_psfhat'].astype(cdt(rdt))
+    x = g[f'c{c}_x'].astype(rdt)
+    beam = g[f'c{c}_beam'].astype(rdt)
+    tol = TOL_CONV[rdt]
+    xout = np.empty((nx, ny), dtype=rdt)
+    y = amd.psf.psf_convolve_slice(None, None, xout, psfhat[0], Q, x[0])
+    assert y is xout                                   # psf.py:29 aliasing contract
+    assert relerr(y, g[f'c{c}_slice']) < tol
+    xoutc = np.empty(x.shape, dtype=rdt)
+    yc = amd.psf.psf_convolve_cube(None, None, xoutc, psfhat, Q, x)
+    assert yc is xoutc
+    assert relerr(yc, g[f'c{c}_cube']) < tol
+    h = amd.hessian._hessian_psf_slice(None, None, None, psfhat[1], beam[1], Q, x[1],
+                                       sigmainv=0.37, wsum=2.5)
+    assert relerr(h, g[f'c{c}_h_slice_full']) < tol
+    h = amd.hessian._hessian_psf_slice(None, None, None, psfhat[1], None, Q, x[1], sigmainv=0.0)
+    assert relerr(h, g[f'c{c}_h_slice_bare']) < tol
+    h = amd.hessian.hessian_psf_cube(None, None, None, beam, psfhat, Q, x, sigmainv=1.25, wsum=3.0)
+    assert relerr(h, g[f'c{c}_h_cube_full']) < tol
+    h = amd.hessian.hessian_psf_cube(None, None, None, None, psfhat, Q, x, sigmainv=0.5)
+    assert relerr(h, g[f'c{c}_h_cube_bare']) < tol
+    assert h.dtype == rdt
+
+
+SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing, ragged
+    (64, 64, 128, 128), (128, 32, 256, 64), (256, 512, 512, 1024), (30, 50, 60, 100),
+    (45, 33, 90, 66), (50, 21, 70, 44), (100, 128, 200, 256), (33, 17, 64, 32),
+    (64, 64, 96, 80), (7, 5, 14, 10), (1, 1, 2, 2), (250, 78, 500, 156), (63, 64, 128, 128),
+]
+
+
+@pmp('rdt', [np.float64, np.float32])
+@pmp('size', SIZES)
+def test_conv_vs_oracle_sizes(amd, size, rdt):
+    nx, ny, P, Q = size
+    rng = np.random.default_rng(nx * 1000 + ny)
+    nb = 2
+    psf = rng.standard_normal((nb, P, Q))
+    psf[:, P // 2, Q // 2] += 5
+    psfhat = ofc.psfhat_from_psf(psf)
+    x = rng.standard_normal((nb, nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref = ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x).copy()
+    y = amd.psf.psf_convolve_cube(None, None, None, psfhat.astype(cdt(rdt)), Q, x.astype(rdt))
+    assert relerr(y, ref) < TOL_CONV[rdt]
+
+
+def test_conv_tensor_path_and_fused_dot(amd):
+    """GPU-resident call: xout written in place, x untouched, fused <dot_with, out>."""
+    rng = np.random.default_rng(7)
+    nb, nx, ny, P, Q = 3, 64, 32, 128, 64
+    psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
+    x = rng.standard_normal((nb, nx, ny))
+    beam = 0.5 + rng.random((nb, nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref = ofc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, x, sigmainv=0.3, wsum=1.7)
+    dev = torch.device('cuda')
+    xt = torch.from_numpy(x).to(dev)
+    x_keep = xt.clone()
+    plan = amd.psf.PsfConvPlan(torch.from_numpy(psfhat).to(dev), nx, ny, Q)
+    out = torch.empty_like(xt)
+    dot = torch.zeros(1, dtype=torch.float64, device=dev)
+    w = torch.from_numpy(rng.standard_normal(x.shape)).to(dev)
+    res = plan.apply(xt, out=out, beam=torch.from_numpy(beam).to(dev), wsum=1.7, sigmainv=0.3,
+                     dot_with=w, dot_out=dot)
+    assert res.data_ptr() == out.data_ptr()
+    assert torch.equal(xt, x_keep)
+    assert relerr(out.cpu().numpy(), ref) < 1e-12
+    assert abs(dot.item() - np.vdot(w.cpu().numpy(), ref)) < 1e-9 * abs(np.vdot(w.cpu().numpy(), ref))
+    # sub-range of bands on a multi-band plan
+    out1 = plan.apply(xt[1:2], band0=1)
+    xpad, xhat, xout = ofc.make_scratch(psfhat[1], Q, (nx, ny), np.float64)
+    ref1 = ofc.psf_convolve_slice(xpad, xhat, xout, psfhat[1], Q, x[1])
+    assert relerr(out1[0].cpu().numpy(), ref1) < 1e-12
+
+
+def test_conv_errors(amd):
+    from pfb_clean_amd._lib import PfbHipError
+    rng = np.random.default_rng(0)
+    with pytest.raises(PfbHipError):           # odd lastsize is outside the supported set
+        amd.psf.PsfConvPlan(rng.standard_normal((1, 16, 6)).astype(np.complex128), 8, 4, 10 + 1)
+    with pytest.raises(PfbHipError):           # prime factor 17
+        amd.psf.PsfConvPlan(np.zeros((1, 34, 9), dtype=np.complex128), 17, 8, 16)
+    with pytest.raises(ValueError):
+        amd.psf.psf_convolve_cube(None, None, None, np.zeros((2, 16, 9), complex), 16,
+                                  np.zeros((3, 8, 8)))
+    psfhat = np.zeros((2, 16, 9), dtype=np.complex128)
+    with pytest.raises(ValueError, match='Beam has incorrect shape'):
+        amd.hessian.hessian_psf_cube(None, None, None, np.zeros((2, 8, 7)), psfhat, 16,
+                                     np.zeros((2, 8, 8)))
+
+
+# -------------------------------------------------------------- vector kernels
+@pmp('rdt', [np.float64, np.float32])
+@pmp('n', [1, 7, 64, 1000, 4099, 1 << 20, (1 << 20) + 3])
+def test_vector_kernels(amd, n, rdt):
+    from pfb_clean_amd import _lib, _dev
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal(n).astype(rdt)
+    b = rng.standard_normal(n).astype(rdt)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ws, out = _dev.scratch()
+    code = _dev.code(ta.dtype)
+    _lib.check(lib.pfb_dot(code, ta.data_ptr(), tb.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    ref = np.dot(a.astype(np.float64), b.astype(np.float64))
+    assert abs(out[0].item() - ref) <= 1e-12 * max(1.0, np.abs(a.astype(np.float64) * b).sum())
+    _lib.check(lib.pfb_norm_diff_sums(code, ta.data_ptr(), tb.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    num, den = out[:2].tolist()
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    assert abs(num - np.sum((a64 - b64) ** 2)) <= 1e-12 * np.sum((a64 - b64) ** 2) + 1e-300
+    assert abs(den - np.sum(a64 ** 2)) <= 1e-12 * np.sum(a64 ** 2)
+    _lib.check(lib.pfb_any_nonzero(code, ta.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    assert out[0].item() > 0
+    z = torch.zeros_like(ta)
+    _lib.check(lib.pfb_any_nonzero(code, z.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    assert out[0].item() == 0
+    _lib.check(lib.pfb_axpby(code, 0.5, ta.data_ptr(), -2.0, tb.data_ptr(), n, _dev.stream()))
+    np.testing.assert_allclose(tb.cpu().numpy(), rdt(0.5) * a + rdt(-2.0) * b, rtol=1e-6 if rdt == np.float32 else 1e-14)
+    # deterministic: same input, bitwise same result
+    _lib.check(lib.pfb_dot(code, ta.data_ptr(), ta.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    d1 = out[0].item()
+    _lib.check(lib.pfb_dot(code, ta.data_ptr(), ta.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _dev.stream()))
+    assert out[0].item() == d1
+
+
+def test_norm_diff_api(amd):
+    rng = np.random.default_rng(3)
+    x, xp = rng.standard_normal((2, 40, 50)), rng.standard_normal((2, 40, 50))
+    assert abs(amd.misc.norm_diff(x, xp) - osv.norm_diff(x, xp)) < 1e-14
+    assert abs(amd.misc.norm_diff(torch.from_numpy(x[0]).cuda(), torch.from_numpy(xp[0]).cuda())
+               - osv.norm_diff(x[0], xp[0])) < 1e-14
+    with pytest.raises(ValueError):
+        amd.misc.norm_diff(x[0, 0], xp[0, 0])
+
+
+# ------------------------------------------------------------------------ pcg
+@pmp('rdt', [np.float64, np.float32])
+def test_pcg_psf_band_history_golden(amd, golden, rdt):
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'].astype(cdt(rdt)), g['b'].astype(rdt), g['beam'].astype(rdt)
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    tol = TOL_PCG[rdt]
+    for tag, bm in (('nobeam', None), ('beam', beam)):
+        for k in (1, 2, 5, 20):
+            for bt in (True, False):
+                m = amd.pcg.pcg_psf(psfhat, b, np.zeros_like(b), bm, Q, 1, sigmainv,
+                                    dict(tol=0.0, maxit=k, minit=k, verbosity=0, backtrack=bt))
+                assert m.dtype == rdt
+                assert relerr(m, g[f'band_{tag}_k{k}_bt{int(bt)}']) < tol, (tag, k, bt)
+    if rdt == np.float64:       # exit iteration is tolerance-controlled: fp64 only
+        for key, minit in (('band_tol1e-2', 1), ('band_tol1e-2_minit15', 15)):
+            m = amd.pcg.pcg_psf(psfhat, b, np.zeros_like(b), None, Q, 1, sigmainv,
+                                dict(tol=1e-2, maxit=100, minit=minit, verbosity=0, backtrack=True))
+            assert relerr(m, g[key]) < tol
+
+
+@pmp('rdt', [np.float64, np.float32])
+def test_pcg_cube_golden_via_reference_call_pattern(amd, golden, rdt):
+    """The exact construction fluxmop.py:160-199 uses -- functools.partial of
+    hessian_psf_cube with scratch buffers -- must take the fused path and match."""
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'].astype(cdt(rdt)), g['b'].astype(rdt), g['beam'].astype(rdt)
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    tol = TOL_PCG[rdt]
+    A = partial(amd.hessian.hessian_psf_cube, None, None, None, beam, psfhat, Q,
+                nthreads=1, sigmainv=sigmainv, wsum=1.0)
+    assert amd.pcg._as_hessian(A, b) is not None
+    for k in (1, 3, 10, 25):
+        x, r = amd.pcg.pcg(A, beam * b, np.zeros_like(b), tol=0.0, maxit=k, minit=k,
+                           verbosity=0, backtrack=True, return_resid=True)
+        assert relerr(x, g[f'cube_k{k}_x']) < tol
+        assert relerr(r, g[f'cube_k{k}_r']) < 10 * tol
+    x0 = g['cube_x0'].astype(rdt)
+    x = amd.pcg.pcg(A, beam * b, x0, M=amd.pcg.DivPrecond(sigmainv), tol=0.0, maxit=7, minit=7,
+                    verbosity=0)
+    assert relerr(x, g['cube_M_x0_k7']) < tol
+    # generic path (opaque callables) agrees with the fused one
+    xg = amd.pcg.pcg(lambda v: A(v), beam * b, x0, M=lambda v: v / rdt(sigmainv), tol=0.0,
+                     maxit=7, minit=7, verbosity=0)
+    assert relerr(xg, g['cube_M_x0_k7']) < tol
+    # zero residual: x0 itself comes back (pcg.py:73-75)
+    xz = amd.pcg.pcg(A, A(x0), x0, tol=1e-5, maxit=5, minit=1, verbosity=0)
+    assert xz is x0
+
+
+def test_pcg_backtracking_golden(amd, golden):
+    g = golden('pcg')
+    ph, bb = g['indef_psfhat'], g['indef_b']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nx, ny = bb.shape
+    A = amd.hessian.HessianPsf(ph, nx, ny, Q, sigmainv=sigmainv)
+    total_bt = 0
+    for bt in (True, False):
+        for k in (3, 8):
+            x, _, res = amd.pcg.pcg_fused(A, torch.from_numpy(bb).cuda(), None, tol=0.0, maxit=k,
+                                          minit=k, backtrack=bt)
+            assert relerr(x.cpu().numpy(), g[f'indef_k{k}_bt{int(bt)}']) < 1e-8
+            assert res.iters == k and res.matvecs == k + 1
+            total_bt += res.backtracks
+    assert total_bt > 0
+
+
+def test_pcg_tensor_inputs_stay_on_device(amd, golden):
+    g = golden('pcg')
+    psfhat, b = torch.from_numpy(g['psfhat']).cuda(), torch.from_numpy(g['b']).cuda()
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nb, nx, ny = b.shape
+    A = amd.hessian.HessianPsf(psfhat, nx, ny, Q, sigmainv=sigmainv, wsum=1.0)
+    x = amd.pcg.pcg(A, b, None, tol=0.0, maxit=5, minit=5, verbosity=0)
+    assert isinstance(x, torch.Tensor) and x.is_cuda
+    xpad, xhat, xout = ofc.make_scratch(g['psfhat'], Q, g['b'].shape, np.float64)
+    ref = osv.pcg(lambda v: ofc.hessian_psf_cube(xpad, xhat, xout, None, g['psfhat'], Q, v,
+                                                 sigmainv=sigmainv, wsum=1.0),
+                  g['b'], None, tol=0.0, maxit=5, minit=5)
+    assert relerr(x.cpu().numpy(), ref) < 1e-9
+
+
+def test_power_method_golden(amd, golden):
+    g = golden('pcg')
+    psfhat, Q, b0 = g['psfhat'], int(g['Q']), g['pm_b0']
+    conv = partial(amd.psf.psf_convolve_cube, None, None, None, psfhat, Q)
+    beta, bvec = amd.pm.power_method(conv, b0.shape, b0=b0.copy(), tol=1e-3, maxit=40, verbosity=0)
+    assert abs(beta - float(g['pm_beta'])) < 1e-10 * abs(float(g['pm_beta']))
+    assert relerr(bvec, g['pm_b']) < 1e-9
+    # device-resident form
+    convt = partial(amd.psf.psf_convolve_cube, None, None, None, torch.from_numpy(psfhat).cuda(), Q)
+    beta2, b2 = amd.pm.power_method(convt, b0.shape, b0=torch.from_numpy(b0).cuda(), tol=1e-3,
+                                    maxit=40, verbosity=0)
+    assert abs(beta2 - beta) < 1e-12 * abs(beta) and b2.is_cuda
