@@ -96,6 +96,13 @@ int pfb_psfconv_apply(pfb_conv_plan* plan, int band0, int nb,
 int    pfb_psfconv_plan_info(const pfb_conv_plan* plan, int* fast_path, int* vb,
                              size_t* workspace_bytes);
 
+/* Per-stage timing for benchmarks: while on, every apply records HIP events on its
+ * stream around the three kernels (row-forward, column, row-inverse); get_profile
+ * waits for them, returns the summed milliseconds per stage and the number of applies
+ * covered (at most 512 between calls), and resets the counters. */
+int pfb_psfconv_set_profiling(pfb_conv_plan* plan, int on);
+int pfb_psfconv_get_profile(pfb_conv_plan* plan, double stage_ms[3], int* napply);
+
 /* ------------------------------------------------------------- CG vector kernels
  * Fused replacements for the numpy passes of pfb/opt/pcg.py:77-111 and
  * pfb/utils/misc.py:1316-1351 (norm_diff).  `ws` is a caller-provided device

@@ -42,6 +42,8 @@ SIGNATURES = {
     'pfb_psfconv_set_psfhat': (_i, [_vp, _vp, _vp]),
     'pfb_psfconv_apply': (_i, [_vp, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
     'pfb_psfconv_plan_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz)]),
+    'pfb_psfconv_set_profiling': (_i, [_vp, _i]),
+    'pfb_psfconv_get_profile': (_i, [_vp, C.POINTER(_d), C.POINTER(_i)]),
     'pfb_dot': (_i, [_i, _vp, _vp, _sz, _vp, _vp, _vp]),
     'pfb_norm_diff_sums': (_i, [_i, _vp, _vp, _sz, _vp, _vp, _vp]),
     'pfb_any_nonzero': (_i, [_i, _vp, _sz, _vp, _vp, _vp]),

@@ -1,0 +1,265 @@
+// fft_pow2.hpp -- register-resident power-of-two complex FFT shared by a group of
+// TPB = N/E threads (wave64-agnostic: groups may be a fraction of a wave or several).
+//
+// Thread t of the group holds element t + TPB*j in register j (j < E) on entry AND on
+// exit (natural order both ways -> coalesced global access with no reordering pass).
+// The transform is a Stockham autosort: radix-min(E, remaining) passes done entirely
+// in registers, with one LDS exchange between consecutive passes:
+//     write  lds[(i-k) R + k + s P]   (i = t + TPB q butterfly, k = i mod P, s < R)
+//     read   reg j <- lds[t + TPB j]
+// LDS rows are padded by one element every 16 (index + index/16) which makes both the
+// strided scatter and the unit-stride gather bank-conflict free for 8- and 16-byte
+// elements (guide: ds_write_b64 / ds_read_b64 lane groups).
+//
+// Twiddles come from a per-plan table with, for every pass s >= 1 and m in {0,1,2,3},
+//     ptw[off_s + m P_s + k] = exp(-2 pi i 2^m k / (P_s R_s)),   k < P_s
+// so each butterfly does 4 coalesced loads (w, w^2, w^4, w^8) and forms the other
+// powers with <= 3 chained complex multiplies (error <= ~5 ulp, measured 2.4).
+#pragma once
+#include "common.hpp"
+
+namespace pfb {
+
+constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
+constexpr int imin(int a, int b) { return a < b ? a : b; }
+
+// radix of the pass that starts with P elements already combined
+template <int N, int E, int P> struct PassRadix { static constexpr int R = imin(E, N / P); };
+
+// offset (in elements) of pass-with-product-P's twiddle block inside the ptw table
+template <int N, int E, int P>
+struct PtwOffset {
+    // passes before this one: products 1 (no twiddles), E, E^2, ...
+    static constexpr int prev = P / E;          // product at the previous pass (P = prev * E)
+    static constexpr int value = (P <= E) ? 0 : PtwOffset<N, E, (P / E < 1 ? 1 : P / E)>::value + 4 * prev;
+};
+template <int N, int E> struct PtwOffset<N, E, 1> { static constexpr int value = 0; };
+
+template <int N, int E>
+constexpr int ptw_total() {
+    int tot = 0;
+    for (int P = E; P < N; P *= E) tot += 4 * P;
+    return tot;
+}
+
+// host: fill the table (long double accuracy, rounded once)
+template <typename T, int N, int E>
+void fill_ptw(cplx<T>* out) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    int off = 0;
+    for (int P = E; P < N; P *= E) {
+        const int R = imin(E, N / P);
+        for (int m = 0; m < 4; ++m)
+            for (int k = 0; k < P; ++k) {
+                long double a = two_pi * (long double)((long long)(1 << m) * k) / (long double)((long long)P * R);
+                out[off + m * P + k] = cplx<T>((T)cosl(a), (T)(-sinl(a)));
+            }
+        off += 4 * P;
+    }
+}
+
+// ------------------------------------------------------------- small in-register DFTs
+template <typename T, bool INV>
+__device__ __forceinline__ cplx<T> rot90(cplx<T> a) {   // multiply by -i (fwd) / +i (inv)
+    return INV ? cplx<T>(-a.y, a.x) : cplx<T>(a.y, -a.x);
+}
+
+template <typename T, bool INV>
+__device__ __forceinline__ void dft2(cplx<T>& a, cplx<T>& b) {
+    cplx<T> t = a - b;
+    a = a + b;
+    b = t;
+}
+
+template <typename T, bool INV>
+__device__ __forceinline__ void dft4(cplx<T>& a0, cplx<T>& a1, cplx<T>& a2, cplx<T>& a3) {
+    cplx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<T, INV>(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+
+// multiply by exp(-+ 2 pi i m / 16) with compile-time m
+template <typename T, bool INV, int m>
+__device__ __forceinline__ cplx<T> mul_w16(cplx<T> a) {
+    constexpr T c = T(0.92387953251128675612818318939678828682L);
+    constexpr T s = T(0.38268343236508977172845998403039886676L);
+    constexpr T h = T(0.70710678118654752440084436210484903928L);
+    constexpr int mm = m & 15;
+    if constexpr (mm == 0) return a;
+    else if constexpr (mm == 4) return rot90<T, INV>(a);
+    else if constexpr (mm == 8) return cplx<T>(-a.x, -a.y);
+    else if constexpr (mm == 12) return rot90<T, !INV>(a);
+    else {
+        // w = (wr, -wi) forward, (wr, +wi) inverse
+        constexpr T wr = (mm == 1) ? c : (mm == 2) ? h : (mm == 3) ? s : (mm == 5) ? -s : (mm == 6) ? -h
+                       : (mm == 7) ? -c : (mm == 9) ? -c : (mm == 10) ? -h : (mm == 11) ? -s
+                       : (mm == 13) ? s : (mm == 14) ? h : c;
+        constexpr T wi = (mm == 1) ? s : (mm == 2) ? h : (mm == 3) ? c : (mm == 5) ? c : (mm == 6) ? h
+                       : (mm == 7) ? s : (mm == 9) ? -s : (mm == 10) ? -h : (mm == 11) ? -c
+                       : (mm == 13) ? -c : (mm == 14) ? -h : -s;
+        const T wy = INV ? wi : -wi;
+        return cplx<T>(a.x * wr - a.y * wy, a.x * wy + a.y * wr);
+    }
+}
+
+template <typename T, bool INV, int R> struct Dft;
+
+template <typename T, bool INV> struct Dft<T, INV, 2> {
+    __device__ __forceinline__ static void run(cplx<T> (&u)[2]) { dft2<T, INV>(u[0], u[1]); }
+};
+template <typename T, bool INV> struct Dft<T, INV, 4> {
+    __device__ __forceinline__ static void run(cplx<T> (&u)[4]) { dft4<T, INV>(u[0], u[1], u[2], u[3]); }
+};
+template <typename T, bool INV> struct Dft<T, INV, 8> {
+    // n = nl + 2 nh : inner dft4 over nh, twiddle w8^(nl k1), outer dft2 over nl -> X[k1 + 4 k2]
+    __device__ __forceinline__ static void run(cplx<T> (&u)[8]) {
+        dft4<T, INV>(u[0], u[2], u[4], u[6]);
+        dft4<T, INV>(u[1], u[3], u[5], u[7]);
+        u[3] = mul_w16<T, INV, 2>(u[3]);
+        u[5] = mul_w16<T, INV, 4>(u[5]);
+        u[7] = mul_w16<T, INV, 6>(u[7]);
+        // now b[nl][k1] sits in u[nl + 2 k1]
+        cplx<T> x[8];
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            cplx<T> p = u[2 * k1], q = u[2 * k1 + 1];
+            x[k1] = p + q;
+            x[k1 + 4] = p - q;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = x[k];
+    }
+};
+template <typename T, bool INV> struct Dft<T, INV, 16> {
+    // n = nl + 4 nh : inner dft4 over nh (b[nl][k1] in u[nl + 4 k1]), twiddle w16^(nl k1),
+    // outer dft4 over nl -> X[k1 + 4 k2]
+    __device__ __forceinline__ static void run(cplx<T> (&u)[16]) {
+        dft4<T, INV>(u[0], u[4], u[8], u[12]);
+        dft4<T, INV>(u[1], u[5], u[9], u[13]);
+        dft4<T, INV>(u[2], u[6], u[10], u[14]);
+        dft4<T, INV>(u[3], u[7], u[11], u[15]);
+        u[5] = mul_w16<T, INV, 1>(u[5]);   u[6] = mul_w16<T, INV, 2>(u[6]);   u[7] = mul_w16<T, INV, 3>(u[7]);
+        u[9] = mul_w16<T, INV, 2>(u[9]);   u[10] = mul_w16<T, INV, 4>(u[10]); u[11] = mul_w16<T, INV, 6>(u[11]);
+        u[13] = mul_w16<T, INV, 3>(u[13]); u[14] = mul_w16<T, INV, 6>(u[14]); u[15] = mul_w16<T, INV, 9>(u[15]);
+        // outer: for each k1 combine u[0 + 4k1], u[1 + 4k1], u[2 + 4k1], u[3 + 4k1] -> X[k1 + 4 k2]
+        dft4<T, INV>(u[0], u[1], u[2], u[3]);       // k1 = 0 -> X[0], X[4], X[8], X[12]
+        dft4<T, INV>(u[4], u[5], u[6], u[7]);       // k1 = 1 -> X[1], X[5], X[9], X[13]
+        dft4<T, INV>(u[8], u[9], u[10], u[11]);     // k1 = 2 -> X[2], X[6], X[10], X[14]
+        dft4<T, INV>(u[12], u[13], u[14], u[15]);   // k1 = 3 -> X[3], X[7], X[11], X[15]
+        // u[4 k1 + k2] = X[k1 + 4 k2]  -> transpose the 4x4 index to natural order
+        cplx<T> t;
+        t = u[1];  u[1] = u[4];   u[4] = t;
+        t = u[2];  u[2] = u[8];   u[8] = t;
+        t = u[3];  u[3] = u[12];  u[12] = t;
+        t = u[6];  u[6] = u[9];   u[9] = t;
+        t = u[7];  u[7] = u[13];  u[13] = t;
+        t = u[11]; u[11] = u[14]; u[14] = t;
+    }
+};
+
+// ------------------------------------------------------------------- the group FFT
+template <typename T, int N, int E>
+struct RegFft {
+    static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
+    static constexpr int TPB = N / E;
+    static constexpr int LDS_ELEMS = N + N / 16;
+    static constexpr int PTW = ptw_total<N, E>();
+
+    __device__ __forceinline__ static int pad(int i) { return i + (i >> 4); }
+    // pad(b + c) == pad(b) + cpad(c) whenever (b & 15) + (c & 15) < 16, which holds for
+    // every (base, constant) pair used below; it lets the 16 LDS accesses of a thread
+    // share ONE address register with compile-time immediates.
+    static constexpr int cpad(int c) { return c + (c >> 4); }
+
+    // twiddle + butterflies of the pass whose predecessor product is P
+    template <bool INV, int P>
+    __device__ __forceinline__ static void butterflies(cplx<T> (&v)[E], int t, const cplx<T>* __restrict__ ptw) {
+        constexpr int R = PassRadix<N, E, P>::R;
+        constexpr int NB = E / R;                 // butterflies per thread
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            cplx<T> u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = v[q + r * NB];
+            if constexpr (P > 1) {
+                const int k = (t + TPB * q) & (P - 1);
+                const cplx<T>* tb = ptw + PtwOffset<N, E, P>::value + k;
+                // w, w^2, w^4, w^8 are loaded; the other powers are formed right where
+                // they are consumed so that only a handful of twiddles is live at a time
+                cplx<T> w1 = tb[0], w2, w4, w8;
+                if constexpr (R > 2) w2 = tb[P];
+                if constexpr (R > 4) w4 = tb[2 * P];
+                if constexpr (R > 8) w8 = tb[3 * P];
+                if constexpr (INV) {
+                    w1.y = -w1.y;
+                    if constexpr (R > 2) w2.y = -w2.y;
+                    if constexpr (R > 4) w4.y = -w4.y;
+                    if constexpr (R > 8) w8.y = -w8.y;
+                }
+                u[1] = u[1] * w1;
+                if constexpr (R > 2) {
+                    u[2] = u[2] * w2;
+                    const cplx<T> w3 = w1 * w2;
+                    u[3] = u[3] * w3;
+                    if constexpr (R > 4) {
+                        u[4] = u[4] * w4;
+                        const cplx<T> w7 = w3 * w4;
+                        u[7] = u[7] * w7;
+                        if constexpr (R > 8) { u[11] = u[11] * (w3 * w8); u[15] = u[15] * (w7 * w8); }
+                        const cplx<T> w5 = w1 * w4;
+                        u[5] = u[5] * w5;
+                        if constexpr (R > 8) u[13] = u[13] * (w5 * w8);
+                        const cplx<T> w6 = w2 * w4;
+                        u[6] = u[6] * w6;
+                        if constexpr (R > 8) {
+                            u[14] = u[14] * (w6 * w8);
+                            u[8] = u[8] * w8;
+                            u[9] = u[9] * (w1 * w8);
+                            u[10] = u[10] * (w2 * w8);
+                            u[12] = u[12] * (w4 * w8);
+                        }
+                    }
+                }
+            }
+            Dft<T, INV, R>::run(u);
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[q + r * NB] = u[r];
+        }
+    }
+
+    template <bool INV, int P>
+    __device__ __forceinline__ static void pass(cplx<T> (&v)[E], cplx<T>* lds, int t,
+                                                const cplx<T>* __restrict__ ptw) {
+        constexpr int R = PassRadix<N, E, P>::R;
+        constexpr int NB = E / R;
+        butterflies<INV, P>(v, t, ptw);
+        if constexpr (P * R < N) {
+            __syncthreads();                       // previous readers of `lds` are done
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int i = t + TPB * q;
+                const int k = i & (P - 1);
+                cplx<T>* wp = lds + pad((i - k) * R + k);
+#pragma unroll
+                for (int s = 0; s < R; ++s) wp[cpad(s * P)] = v[q + s * NB];
+            }
+            __syncthreads();
+            const cplx<T>* rp = lds + pad(t);
+#pragma unroll
+            for (int j = 0; j < E; ++j) v[j] = rp[cpad(TPB * j)];
+            pass<INV, P * R>(v, lds, t, ptw);
+        }
+    }
+
+    // All threads of the WORKGROUP must call (contains __syncthreads); `lds` is this
+    // group's private LDS_ELEMS buffer.
+    template <bool INV>
+    __device__ __forceinline__ static void run(cplx<T> (&v)[E], cplx<T>* lds, int t,
+                                               const cplx<T>* __restrict__ ptw) {
+        pass<INV, 1>(v, lds, t, ptw);
+    }
+};
+
+}  // namespace pfb

@@ -33,6 +33,9 @@ int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* b
                double scale, double sigmainv, void* out, const void* dot_with,
                hipStream_t st);
 int pow2_prepare(pfb_conv_plan* p);
+void pow2_release(pfb_conv_plan* p);
+int pow2_rows_per_wg(const pfb_conv_plan* p);
+int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st);
 
 struct ConvDims {
     int nx, ny, P, Q, M, VB, nvb;
@@ -199,16 +202,20 @@ static int apply_generic(pfb_conv_plan* p, int band0, int nb, const void* x, con
     const ConvDims d = dims_of(p);
     const size_t lds_row = 64 + 2 * sizeof(cplx<T>) * (size_t)p->M;
     const size_t lds_col = 2 * sizeof(cplx<T>) * (size_t)p->P;
+    prof_mark(p, st, 0);
     hipLaunchKernelGGL((k_row_fwd_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
                        (const T*)x, (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)p->twQ,
                        d, p->frow, band0);
+    prof_mark(p, st, 1);
     hipLaunchKernelGGL((k_col_generic<T>), dim3(p->M + 1, nb), dim3(256), lds_col, st,
                        (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
                        d, p->fcol, band0);
+    prof_mark(p, st, 2);
     hipLaunchKernelGGL((k_row_inv_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const T*)x,
                        (const T*)beam, (const T*)dot_with, (T*)out, p->partials, d, p->frow,
                        band0, (T)scale, (T)sigmainv);
+    prof_mark(p, st, 3);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
@@ -255,8 +262,9 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
     const size_t csz = dtype == PFB_F32 ? 8 : 16;
     p->fast = pow2_supported(p) ? 1 : 0;
     if (const char* e = getenv("PFB_FORCE_GENERIC")) { if (atoi(e)) p->fast = 0; }
-    int vb = p->fast ? 2 : 1;
-    if (const char* e = getenv("PFB_VB")) { int t = atoi(e); if (t >= 1 && t <= 16) vb = t; }
+    int vb = 1;                 // the pow2 kernels are written for VB = 1 (pure transposed T)
+    if (!p->fast) { if (const char* e = getenv("PFB_VB")) { int t = atoi(e); if (t >= 1 && t <= 16) vb = t; } }
+    p->partials_per_band = p->fast ? nx / pow2_rows_per_wg(p) : nx;
     p->VB = vb;
     p->nvb = (p->M + 1 + vb - 1) / vb;
     p->T_elems_per_band = (size_t)p->nvb * nx * vb;
@@ -305,6 +313,11 @@ int pfb_psfconv_plan_destroy(pfb_conv_plan* p) {
     if (p->psf_l) (void)hipFree(p->psf_l);
     if (p->T) (void)hipFree(p->T);
     if (p->partials) (void)hipFree(p->partials);
+    pow2_release(p);
+    if (p->prof_ev) {
+        for (int k = 0; k < 4 * PROF_MAX; ++k) (void)hipEventDestroy(p->prof_ev[k]);
+        free(p->prof_ev);
+    }
     free(p);
     return PFB_OK;
 }
@@ -317,8 +330,41 @@ int pfb_psfconv_plan_info(const pfb_conv_plan* p, int* fast_path, int* vb, size_
     return PFB_OK;
 }
 
+int pfb_psfconv_set_profiling(pfb_conv_plan* p, int on) {
+    PFB_REQUIRE(p != nullptr, PFB_ERR_INVALID, "set_profiling: null plan");
+    if (on && !p->prof_ev) {
+        p->prof_ev = (hipEvent_t*)calloc(4 * PROF_MAX, sizeof(hipEvent_t));
+        PFB_REQUIRE(p->prof_ev != nullptr, PFB_ERR_ALLOC, "set_profiling: host alloc failed");
+        for (int k = 0; k < 4 * PROF_MAX; ++k) PFB_HIP_CHECK(hipEventCreate(&p->prof_ev[k]));
+    }
+    p->prof_on = on ? 1 : 0;
+    p->prof_n = 0;
+    return PFB_OK;
+}
+
+int pfb_psfconv_get_profile(pfb_conv_plan* p, double* stage_ms, int* napply) {
+    PFB_REQUIRE(p && stage_ms && napply, PFB_ERR_INVALID, "get_profile: null argument");
+    stage_ms[0] = stage_ms[1] = stage_ms[2] = 0.0;
+    *napply = p->prof_n;
+    for (int a = 0; a < p->prof_n; ++a) {
+        PFB_HIP_CHECK(hipEventSynchronize(p->prof_ev[a * 4 + 3]));
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            PFB_HIP_CHECK(hipEventElapsedTime(&ms, p->prof_ev[a * 4 + k], p->prof_ev[a * 4 + k + 1]));
+            stage_ms[k] += ms;
+        }
+    }
+    p->prof_n = 0;
+    return PFB_OK;
+}
+
 int pfb_psfconv_set_psfhat(pfb_conv_plan* p, const void* psfhat, void* stream) {
     PFB_REQUIRE(p && psfhat, PFB_ERR_INVALID, "set_psfhat: null argument");
+    if (p->fast) {
+        int rc = pow2_set_psfhat(p, psfhat, as_stream(stream));
+        if (rc == PFB_OK) p->have_psf = 1;
+        return rc;
+    }
     const ConvDims d = dims_of(p);
     dim3 grid((p->nvb * p->VB + 63) / 64, p->P, p->nband);
     if (p->dtype == PFB_F32)
@@ -353,7 +399,7 @@ int pfb_psfconv_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const 
         rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
     if (rc != PFB_OK) return rc;
     if (dot_with) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials, p->nx * nb, dot_out);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials, p->partials_per_band * nb, dot_out);
         PFB_HIP_CHECK(hipGetLastError());
     }
     return PFB_OK;

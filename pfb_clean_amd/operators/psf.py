@@ -92,6 +92,16 @@ class PsfConvPlan:
             _dev.ptr(dot_with), _dev.ptr(dot_out), _dev.stream()))
         return out3[0] if squeeze else out3
 
+    def set_profiling(self, on):
+        _lib.check(self._lib.pfb_psfconv_set_profiling(self._h, int(bool(on))))
+
+    def get_profile(self):
+        """(ms_row_fwd, ms_col, ms_row_inv) summed over `napply` applies, napply."""
+        ms = (C.c_double * 3)()
+        n = C.c_int()
+        _lib.check(self._lib.pfb_psfconv_get_profile(self._h, ms, C.byref(n)))
+        return tuple(ms), n.value
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             torch.cuda.synchronize()

@@ -84,6 +84,9 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
     (64, 64, 128, 128), (128, 32, 256, 64), (256, 512, 512, 1024), (30, 50, 60, 100),
     (45, 33, 90, 66), (50, 21, 70, 44), (100, 128, 200, 256), (33, 17, 64, 32),
     (64, 64, 96, 80), (7, 5, 14, 10), (1, 1, 2, 2), (250, 78, 500, 156), (63, 64, 128, 128),
+    # power-of-two with 2x oversampling: the register-resident fast path
+    (64, 128, 128, 256), (128, 256, 256, 512), (512, 128, 1024, 256), (1024, 1024, 2048, 2048),
+    (2048, 256, 4096, 512), (256, 4096, 512, 8192), (4096, 128, 8192, 256),
 ]
 
 
@@ -103,10 +106,12 @@ def test_conv_vs_oracle_sizes(amd, size, rdt):
     assert relerr(y, ref) < TOL_CONV[rdt]
 
 
-def test_conv_tensor_path_and_fused_dot(amd):
+@pmp('shape', [(3, 64, 32), (3, 256, 512)])      # generic path, fast path
+def test_conv_tensor_path_and_fused_dot(amd, shape):
     """GPU-resident call: xout written in place, x untouched, fused <dot_with, out>."""
     rng = np.random.default_rng(7)
-    nb, nx, ny, P, Q = 3, 64, 32, 128, 64
+    nb, nx, ny = shape
+    P, Q = 2 * nx, 2 * ny
     psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
     x = rng.standard_normal((nb, nx, ny))
     beam = 0.5 + rng.random((nb, nx, ny))
@@ -123,6 +128,7 @@ def test_conv_tensor_path_and_fused_dot(amd):
                      dot_with=w, dot_out=dot)
     assert res.data_ptr() == out.data_ptr()
     assert torch.equal(xt, x_keep)
+    assert plan.fast_path == (nx >= 64 and ny >= 128)
     assert relerr(out.cpu().numpy(), ref) < 1e-12
     assert abs(dot.item() - np.vdot(w.cpu().numpy(), ref)) < 1e-9 * abs(np.vdot(w.cpu().numpy(), ref))
     # sub-range of bands on a multi-band plan
@@ -130,6 +136,26 @@ def test_conv_tensor_path_and_fused_dot(amd):
     xpad, xhat, xout = ofc.make_scratch(psfhat[1], Q, (nx, ny), np.float64)
     ref1 = ofc.psf_convolve_slice(xpad, xhat, xout, psfhat[1], Q, x[1])
     assert relerr(out1[0].cpu().numpy(), ref1) < 1e-12
+
+
+@pmp('rdt', [np.float64, np.float32])
+def test_fast_path_equals_generic_path(amd, rdt, monkeypatch):
+    """Same plan sizes through both kernel families (PFB_FORCE_GENERIC picks the coverage
+    kernels): they must agree to rounding, band by band, with beam / wsum / sigmainv."""
+    rng = np.random.default_rng(11)
+    nb, nx, ny = 2, 512, 256
+    P, Q = 2 * nx, 2 * ny
+    psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q))).astype(cdt(rdt))
+    x = rng.standard_normal((nb, nx, ny)).astype(rdt)
+    beam = (0.5 + rng.random((nb, nx, ny))).astype(rdt)
+    amd.psf.clear_plan_cache()
+    fast = amd.hessian.hessian_psf_cube(None, None, None, beam, psfhat, Q, x, sigmainv=0.2, wsum=1.3)
+    monkeypatch.setenv('PFB_FORCE_GENERIC', '1')
+    amd.psf.clear_plan_cache()
+    gen = amd.hessian.hessian_psf_cube(None, None, None, beam, psfhat, Q, x, sigmainv=0.2, wsum=1.3)
+    monkeypatch.delenv('PFB_FORCE_GENERIC')
+    amd.psf.clear_plan_cache()
+    assert relerr(fast, gen) < (1e-13 if rdt == np.float64 else 2e-6)
 
 
 def test_conv_errors(amd):
