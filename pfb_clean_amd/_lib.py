@@ -71,6 +71,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its bundled libamdhip64 must be the HIP runtime of the process (loading
+    # ours first binds /opt/rocm's copy and torch then sees "no ROCm-capable device")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "

@@ -86,10 +86,11 @@ class _Work:
 
 
 def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack=True,
-              return_resid=False, allreduce=None):
+              return_resid=False, group=None, distributed=False):
     """Run pfb_pcg_solve.  b, x0: GPU tensors (nb, nx, ny) | (nx, ny).  Returns
-    (x, r|None, PcgResult).  allreduce: optional callable(tensor_view_of_doubles) that
-    sums in place over ranks (see pfb_clean_amd.dist)."""
+    (x, r|None, PcgResult).  distributed=True: the bands of this call are one rank's
+    shard of a cube solve; every inner product is all-reduced over `group`
+    (pfb_clean_amd.dist.AllReduceHook, RCCL)."""
     lib = _lib.load()
     plan = A.plan
     squeeze = b.ndim == 2
@@ -103,9 +104,12 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
     r = torch.empty_like(b3) if return_resid else None
     work = _Work.get(plan, nb)
     res = _lib.PcgResult()
-    if allreduce is None:
+    if not distributed:
         cb = _lib.ALLREDUCE_FN(0)
     else:
+        from ..dist import AllReduceHook
+        allreduce = AllReduceHook(work, group)
+
         def _hook(ctx, buf, count, stream):
             try:
                 allreduce(buf, count)
