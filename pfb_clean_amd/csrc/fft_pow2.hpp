@@ -229,12 +229,16 @@ struct RegFft {
         }
     }
 
-    template <bool INV, int P>
-    __device__ __forceinline__ static void pass(cplx<T> (&v)[E], cplx<T>* lds, int t,
+    // NV independent transforms advance together: same barriers, NV LDS buffers
+    // (lds + n * LDS_ELEMS), NV * E values in registers.  NV = 1 for the row kernels,
+    // NV = 2 for the column kernel (two frequency columns per 16-byte access).
+    template <bool INV, int P, int NV>
+    __device__ __forceinline__ static void pass(cplx<T> (&v)[NV][E], cplx<T>* lds, int t,
                                                 const cplx<T>* __restrict__ ptw) {
         constexpr int R = PassRadix<N, E, P>::R;
         constexpr int NB = E / R;
-        butterflies<INV, P>(v, t, ptw);
+#pragma unroll
+        for (int n = 0; n < NV; ++n) butterflies<INV, P>(v[n], t, ptw);
         if constexpr (P * R < N) {
             __syncthreads();                       // previous readers of `lds` are done
 #pragma unroll
@@ -243,22 +247,33 @@ struct RegFft {
                 const int k = i & (P - 1);
                 cplx<T>* wp = lds + pad((i - k) * R + k);
 #pragma unroll
-                for (int s = 0; s < R; ++s) wp[cpad(s * P)] = v[q + s * NB];
+                for (int n = 0; n < NV; ++n) {
+#pragma unroll
+                    for (int s = 0; s < R; ++s) wp[n * LDS_ELEMS + cpad(s * P)] = v[n][q + s * NB];
+                }
             }
             __syncthreads();
             const cplx<T>* rp = lds + pad(t);
 #pragma unroll
-            for (int j = 0; j < E; ++j) v[j] = rp[cpad(TPB * j)];
-            pass<INV, P * R>(v, lds, t, ptw);
+            for (int n = 0; n < NV; ++n) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cpad(TPB * j)];
+            }
+            pass<INV, P * R, NV>(v, lds, t, ptw);
         }
     }
 
     // All threads of the WORKGROUP must call (contains __syncthreads); `lds` is this
-    // group's private LDS_ELEMS buffer.
+    // group's private buffer of NV * LDS_ELEMS elements.
+    template <bool INV, int NV>
+    __device__ __forceinline__ static void runN(cplx<T> (&v)[NV][E], cplx<T>* lds, int t,
+                                                const cplx<T>* __restrict__ ptw) {
+        pass<INV, 1, NV>(v, lds, t, ptw);
+    }
     template <bool INV>
     __device__ __forceinline__ static void run(cplx<T> (&v)[E], cplx<T>* lds, int t,
                                                const cplx<T>* __restrict__ ptw) {
-        pass<INV, 1>(v, lds, t, ptw);
+        pass<INV, 1, 1>(reinterpret_cast<cplx<T>(&)[1][E]>(v), lds, t, ptw);
     }
 };
 

@@ -35,6 +35,8 @@ int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* b
 int pow2_prepare(pfb_conv_plan* p);
 void pow2_release(pfb_conv_plan* p);
 int pow2_rows_per_wg(const pfb_conv_plan* p);
+int pow2_nblocks(const pfb_conv_plan* p);
+int pow2_nvb(const pfb_conv_plan* p);
 int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st);
 
 struct ConvDims {
@@ -265,8 +267,13 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
     int vb = 1;                 // the pow2 kernels are written for VB = 1 (pure transposed T)
     if (!p->fast) { if (const char* e = getenv("PFB_VB")) { int t = atoi(e); if (t >= 1 && t <= 16) vb = t; } }
     p->partials_per_band = p->fast ? nx / pow2_rows_per_wg(p) : nx;
+    if (p->fast) {              // 16-byte column blocks per parity class (fftconv_pow2.hip)
+        vb = pow2_nvb(p);
+        p->nvb = pow2_nblocks(p);
+    } else {
+        p->nvb = (p->M + 1 + vb - 1) / vb;
+    }
     p->VB = vb;
-    p->nvb = (p->M + 1 + vb - 1) / vb;
     p->T_elems_per_band = (size_t)p->nvb * nx * vb;
     p->psf_elems_per_band = (size_t)p->nvb * p->P * vb;
     if (!plan_factors(p->M, &p->frow) || !plan_factors(p->P, &p->fcol)) {

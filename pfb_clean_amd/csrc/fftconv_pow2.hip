@@ -11,17 +11,28 @@
 // is ever computed, loaded or stored.  The same identity is used on the packed-real
 // row transform (z[n] = x[2n] + i x[2n+1]).
 //
-// Kernels (VB = 1 layout: T[band][v][i], i contiguous; psf_l[band][v][parity][m]):
-//   k_row_fwd_pow2  G image rows per workgroup -> X[v], written as G*8-byte pieces
-//                   (LDS-transposed) into T[v][i0 .. i0+G)
-//   k_col_pow2      one frequency column per thread group, contiguous 8-byte/lane
-//                   streams: a -> FFT -> *psf_e -> IFFT, a*w -> FFT -> *psf_o -> IFFT,
-//                   combine, store in place
-//   k_row_inv_pow2  G output rows per workgroup, mirror image of row_fwd with the fused
-//                   epilogue (1/(PQ wsum), beam, + sigmainv x, <dot_with, out> partials)
+// Layout (16-byte blocking).  Frequency columns are grouped NVB at a time (2 for fp32,
+// 1 for fp64: NVB complex values = 16 bytes) WITHIN a parity class of the row transform
+// (even bins v = 2m, odd bins v = 2m+1), L = ny/2, NBE = ceil((L+1)/NVB), NBO = L/NVB:
+//     block b <  NBE : even bins m = NVB b + c   (fp32: the last block holds m = L + a dummy)
+//     block b >= NBE : odd  bins m = NVB (b - NBE) + c
+//     T[band][b][i][c]                 c < NVB, i < nx        -> blocks of nx*16 B
+//     psf_l[band][b][pu][mu][c]        psfhat[2 mu + pu][v(b,c)], mu < H = nx
+// so that (measured, tools/micro/piece_bw.hip: 64-B pieces 3.1 TB/s, 128-B pieces
+// 5.5 TB/s from HBM) every strided access is a full 128-byte line: 8 rows x 2 columns.
+//
+// Kernels:
+//   k_row_fwd_pow2  G = 8 image rows per workgroup -> X[v]; per parity the bins are
+//                   LDS-transposed and written as 128-byte pieces T[b][i0..i0+8)[0..1]
+//   k_col_pow2      one block (two columns) per thread group, 16-byte/lane streams:
+//                   a -> FFT -> *psf_e -> IFFT, a*w -> FFT -> *psf_o -> IFFT, combine,
+//                   store in place; the two columns share barriers (RegFft NV = 2)
+//   k_row_inv_pow2  mirror image of row_fwd with the fused epilogue
+//                   (1/(PQ wsum), beam, + sigmainv x, <dot_with, out> partials)
 #include "conv_plan.hpp"
 #include "fft_pow2.hpp"
 #include <vector>
+#include <cstdlib>
 
 namespace pfb {
 
@@ -29,8 +40,10 @@ namespace pfb {
 // is the HBM-streaming kernel), the row kernels favour few threads per row so that 8
 // rows (64-byte transposed pieces) fit one 1024-thread workgroup.
 template <typename T> struct FastCfg;
-template <> struct FastCfg<float>  { static constexpr int ECOL = 8; static constexpr int EROW = 16; static constexpr int WCOL = 4; };
-template <> struct FastCfg<double> { static constexpr int ECOL = 8; static constexpr int EROW = 8;  static constexpr int WCOL = 2; };
+// NVB: frequency columns per block of the T / psf_l layout = columns per 16-byte access
+// (2 x complex64, 1 x complex128), so that 8 rows of a block form one 128-byte line.
+template <> struct FastCfg<float>  { static constexpr int ECOL = 8; static constexpr int EROW = 16; static constexpr int WCOL = 4; static constexpr int NVB = 2; };
+template <> struct FastCfg<double> { static constexpr int ECOL = 8; static constexpr int EROW = 8;  static constexpr int WCOL = 2; static constexpr int NVB = 1; };
 
 constexpr int LDS_BUDGET = 152 * 1024;
 
@@ -46,16 +59,15 @@ constexpr int row_groups() {
 template <int H, int E>
 constexpr int col_groups() { return (H / E) >= 256 ? 1 : 256 / (H / E); }
 
-// two adjacent complex values as one aligned access (16 B for fp32, 2 x 16 B for fp64)
-template <typename T> struct alignas(2 * sizeof(cplx<T>) > 16 ? 16 : 2 * sizeof(cplx<T>)) Pair2 { cplx<T> a, b; };
-template <typename T>
-__device__ __forceinline__ void store2(cplx<T>* dst, cplx<T> a, cplx<T> b) {
-    Pair2<T> p; p.a = a; p.b = b;
-    *reinterpret_cast<Pair2<T>*>(dst) = p;
+// NVB adjacent complex values as one aligned 16-byte access
+template <typename T, int NVB> struct alignas(16) Blk { cplx<T> c[NVB]; };
+template <typename T, int NVB>
+__device__ __forceinline__ Blk<T, NVB> loadb(const cplx<T>* src) {
+    return *reinterpret_cast<const Blk<T, NVB>*>(src);
 }
-template <typename T>
-__device__ __forceinline__ Pair2<T> load2(const cplx<T>* src) {
-    return *reinterpret_cast<const Pair2<T>*>(src);
+template <typename T, int NVB>
+__device__ __forceinline__ void storeb(cplx<T>* dst, const Blk<T, NVB>& b) {
+    *reinterpret_cast<Blk<T, NVB>*>(dst) = b;
 }
 
 // Make a pointer opaque to the optimiser: loads through the result cannot be CSE'd with /
@@ -73,10 +85,19 @@ struct FastDims {
 };
 
 // ---------------------------------------------------------------- psfhat re-layout
-// psf_l[band][v][par][m] = psfhat[band][2m + par][v]      (P = 2H rows, v <= M)
+// column v of the half spectrum -> (block, slot) of the pair layout
+__host__ __device__ inline void block_of_bin(int v, int L, int nvb, int* blk, int* c) {
+    const int m = v >> 1;
+    const int nbe = (L + nvb) / nvb;
+    *blk = ((v & 1) ? nbe : 0) + m / nvb;
+    *c = m % nvb;
+}
+inline int fast_nblocks(int L, int nvb) { return (L + nvb) / nvb + L / nvb; }
+
+// psf_l[band][blk][pu][mu][c] = psfhat[band][2 mu + pu][v]
 template <typename T>
 __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>* __restrict__ psf_l,
-                                    int P, int nv, size_t psf_band) {
+                                    int P, int nv, int L, int nvb, size_t psf_band) {
     // tile transpose through LDS: block handles 32 u x 32 v
     __shared__ cplx<T> tile[32][33];
     const int band = blockIdx.z;
@@ -90,8 +111,11 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
     const int H = P / 2;
     for (int r = ty; r < 32; r += 8) {
         const int v = v0 + r, u = u0 + tx;
-        if (u < P && v < nv)
-            psf_l[(size_t)band * psf_band + (size_t)v * P + (size_t)(u & 1) * H + (u >> 1)] = tile[tx][r];
+        if (u < P && v < nv) {
+            int blk, c;
+            block_of_bin(v, L, nvb, &blk, &c);
+            psf_l[(size_t)band * psf_band + (((size_t)blk * 2 + (u & 1)) * H + (u >> 1)) * nvb + c] = tile[tx][r];
+        }
     }
 }
 
@@ -100,47 +124,203 @@ template <typename T, int H, int E>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), FastCfg<T>::WCOL)
 k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
-           int nv, size_t T_band, size_t psf_band, int band0) {
+           int nblk, size_t T_band, size_t psf_band, int band0) {
     using F = RegFft<T, H, E>;
     constexpr int TPB = F::TPB;
+    constexpr int NVB = FastCfg<T>::NVB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
-    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem) + (size_t)g * F::LDS_ELEMS;
-    const int v = blockIdx.x * col_groups<H, E>() + g;
+    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem) + (size_t)g * (NVB * F::LDS_ELEMS);
+    const int blk = blockIdx.x * col_groups<H, E>() + g;
     const int band = band0 + blockIdx.y;
-    const bool active = v < nv;
-    cplx<T>* col = Tw + (size_t)band * T_band + (size_t)(active ? v : 0) * H;
-    const cplx<T>* pe = psf_l + (size_t)band * psf_band + (size_t)(active ? v : 0) * (2 * H);
-    const cplx<T>* po = pe + H;
+    const bool active = blk < nblk;
+    const size_t b = active ? blk : 0;
+    cplx<T>* col = Tw + (size_t)band * T_band + (b * (size_t)H + t) * NVB;             // [i][c]
+    const cplx<T>* pe = psf_l + (size_t)band * psf_band + (b * (2 * (size_t)H) + t) * NVB;
+    const cplx<T>* po = pe + (size_t)H * NVB;
 
-    cplx<T> vv[E], ev[E];
+    cplx<T> vv[NVB][E], ev[NVB][E];
 #pragma unroll
-    for (int j = 0; j < E; ++j) vv[j] = active ? col[t + TPB * j] : cplx<T>(0, 0);
-    // ---- even bins
-    F::template run<false>(vv, lds, t, ptw);
+    for (int j = 0; j < E; ++j) {
+        Blk<T, NVB> a;
+        if (active) a = loadb<T, NVB>(col + NVB * TPB * j);
 #pragma unroll
-    for (int j = 0; j < E; ++j) vv[j] = vv[j] * pe[t + TPB * j];
-    F::template run<true>(vv, lds, t, ptw);
+        for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] : cplx<T>(0, 0);
+    }
+    // ---- even bins of the column transform
+    F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
-    for (int j = 0; j < E; ++j) ev[j] = vv[j];
-    // ---- odd bins: a .* w_P^n  (a and w re-read: L2 hits, saves 64 live VGPRs)
+    for (int j = 0; j < E; ++j) {
+        const Blk<T, NVB> p = loadb<T, NVB>(pe + NVB * TPB * j);
+#pragma unroll
+        for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
+    }
+    F::template runN<true, NVB>(vv, lds, t, ptw);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+#pragma unroll
+        for (int c = 0; c < NVB; ++c) ev[c][j] = vv[c][j];
+    }
+    // ---- odd bins: a .* w_P^n  (a and w re-read: L2 hits, saves live VGPRs)
     {
-        const cplx<T>* col2 = opaque(col + t);
+        const cplx<T>* col2 = opaque(col);
         const cplx<T>* tw2 = opaque(twP + t);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const cplx<T> a = active ? col2[TPB * j] : cplx<T>(0, 0);
-            vv[j] = a * tw2[TPB * j];
+            Blk<T, NVB> a;
+            if (active) a = loadb<T, NVB>(col2 + NVB * TPB * j);
+            const cplx<T> w = tw2[TPB * j];
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] * w : cplx<T>(0, 0);
         }
     }
-    F::template run<false>(vv, lds, t, ptw);
+    F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
-    for (int j = 0; j < E; ++j) vv[j] = vv[j] * po[t + TPB * j];
-    F::template run<true>(vv, lds, t, ptw);
+    for (int j = 0; j < E; ++j) {
+        const Blk<T, NVB> p = loadb<T, NVB>(po + NVB * TPB * j);
+#pragma unroll
+        for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
+    }
+    F::template runN<true, NVB>(vv, lds, t, ptw);
     if (active) {
         const cplx<T>* tw3 = opaque(twP + t);
 #pragma unroll
-        for (int j = 0; j < E; ++j) col[t + TPB * j] = ev[j] + mulc(vv[j], tw3[TPB * j]);
+        for (int j = 0; j < E; ++j) {
+            const cplx<T> w = tw3[TPB * j];
+            Blk<T, NVB> o;
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) o.c[c] = ev[c][j] + mulc(vv[c][j], w);
+            storeb<T, NVB>(col + NVB * TPB * j, o);
+        }
+    }
+}
+
+// --------------------------------------------------- column, persistent + prefetching
+// The plain column kernel above is latency bound (rocprofv3: 58 % of wave-cycles parked in
+// s_waitcnt / s_barrier, VALU 18 %): every block pays the HBM latency of a, psf_e and psf_o
+// one after the other.  This version keeps ONE workgroup per CU resident (256 VGPRs per
+// thread), loops over the (band, block) items, and has at all times in flight
+//   * psf_e and psf_o of the CURRENT item (issued before the first FFT), and
+//   * a (the T block) of the NEXT item,
+// so that in steady state no load latency is exposed; the column twiddles w_P^n are
+// loaded once per kernel and stay in registers.
+template <typename T, int H, int E>
+__global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), 2)
+k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
+            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
+            int nblk, int nitems, size_t T_band, size_t psf_band, int band0) {
+    using F = RegFft<T, H, E>;
+    constexpr int TPB = F::TPB;
+    constexpr int NVB = FastCfg<T>::NVB;
+    constexpr int GC = col_groups<H, E>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
+    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem) + (size_t)g * (NVB * F::LDS_ELEMS);
+    const int stride = gridDim.x * GC;
+    const int niter = (nitems + stride - 1) / stride;           // same for every workgroup
+
+    cplx<T> tw[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) tw[j] = twP[t + TPB * j];
+
+    auto col_of = [&](int item) -> cplx<T>* {
+        const int bl = item / nblk, blk = item - bl * nblk;
+        return Tw + (size_t)(band0 + bl) * T_band + ((size_t)blk * H + t) * NVB;
+    };
+    auto psf_of = [&](int item) -> const cplx<T>* {
+        const int bl = item / nblk, blk = item - bl * nblk;
+        return psf_l + (size_t)(band0 + bl) * psf_band + ((size_t)blk * 2 * H + t) * NVB;
+    };
+
+    int item = blockIdx.x * GC + g;
+    Blk<T, NVB> an[E];
+    {
+        const bool act = item < nitems;
+        const cplx<T>* c0 = col_of(act ? item : 0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (act) an[j] = loadb<T, NVB>(c0 + NVB * TPB * j);
+            else {
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) an[j].c[c] = cplx<T>(0, 0);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it, item += stride) {
+        const bool active = item < nitems;
+        cplx<T>* col = col_of(active ? item : 0);
+        const cplx<T>* pe = psf_of(active ? item : 0);
+        const cplx<T>* po = pe + (size_t)H * NVB;
+        cplx<T> vv[NVB][E], ev[NVB][E];
+        Blk<T, NVB> qe[E], qo[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = an[j].c[c];
+        }
+        // issue everything this item still needs from HBM, then the next item's a
+#pragma unroll
+        for (int j = 0; j < E; ++j) qe[j] = loadb<T, NVB>(pe + NVB * TPB * j);
+        {
+            const int nxt = item + stride;
+            const bool nact = nxt < nitems;
+            const cplx<T>* cn = col_of(nact ? nxt : 0);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if (nact) an[j] = loadb<T, NVB>(cn + NVB * TPB * j);
+                else {
+#pragma unroll
+                    for (int c = 0; c < NVB; ++c) an[j].c[c] = cplx<T>(0, 0);
+                }
+            }
+        }
+        // a copy of a for the odd-bin pass, pre-multiplied by w_P^n, parked in ev... no:
+        // ev is needed for the even result; the odd input is re-read below (L2 hit).
+        // ---- even bins
+        F::template runN<false, NVB>(vv, lds, t, ptw);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * qe[j].c[c];
+        }
+        // psf_o has the inverse FFT of the even bins and the forward FFT of the odd bins
+        // (~2/3 of the item) to arrive
+#pragma unroll
+        for (int j = 0; j < E; ++j) qo[j] = loadb<T, NVB>(opaque(po) + NVB * TPB * j);
+        F::template runN<true, NVB>(vv, lds, t, ptw);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) ev[c][j] = vv[c][j];
+        }
+        // ---- odd bins: a .* w_P^n (a re-read from L2)
+        {
+            const cplx<T>* col2 = opaque(col);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                Blk<T, NVB> a;
+                if (active) a = loadb<T, NVB>(col2 + NVB * TPB * j);
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] * tw[j] : cplx<T>(0, 0);
+            }
+        }
+        F::template runN<false, NVB>(vv, lds, t, ptw);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * qo[j].c[c];
+        }
+        F::template runN<true, NVB>(vv, lds, t, ptw);
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                Blk<T, NVB> o;
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) o.c[c] = ev[c][j] + mulc(vv[c][j], tw[j]);
+                storeb<T, NVB>(col + NVB * TPB * j, o);
+            }
+        }
     }
 }
 
@@ -159,12 +339,9 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
     constexpr int G = row_groups<T, L, E>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
-    constexpr int HP = G / 2;
-    constexpr int MSTEP = NT / HP;
     using V2 = typename vec2<T>::type;
-    const int rp = threadIdx.x % HP, mi = threadIdx.x / HP;
-    const cplx<T>* r0 = lds0 + (size_t)(2 * rp) * STRIDE;
-    const cplx<T>* r1 = r0 + STRIDE;
+    const int rr = threadIdx.x % G, bi = threadIdx.x / G;      // row in the group, block lane
+    const cplx<T>* zr = lds0 + (size_t)rr * STRIDE;
     cplx<T> vv[E];
     {
         // z[n] = x[2n] + i x[2n+1]  (re-read per parity: an L2 hit that keeps the
@@ -191,22 +368,28 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
     // X[v] = 1/2 [ (Z[v] + conj Z[M-v]) - i w_Q^v (Z[v] - conj Z[M-v]) ]
     //   even v = 2m   : Z -> Ze[m mod L], Ze[(L-m) mod L]      m = 0..L
     //   odd  v = 2m+1 : Z -> Zo[m],       Zo[L-1-m]            m = 0..L-1
-    constexpr int mend = PAR ? L : L + 1;
-    for (int m = mi; m < mend; m += MSTEP) {
-        const int ia = PAR ? m : (m == L ? 0 : m);
-        const int ib = PAR ? (L - 1 - m) : (m == 0 ? 0 : L - m);
-        const int v = 2 * m + PAR;
-        const cplx<T> w = twQ[v];
-        cplx<T> o[2];
+    // each lane produces the NVB bins of block b for ONE row: 16 bytes; the G lanes of a
+    // block lane-group cover rows i0..i0+G-1 -> one contiguous G*16-byte piece of T[b]
+    constexpr int NVB = FastCfg<T>::NVB;
+    constexpr int NBE = (L + NVB) / NVB;
+    constexpr int NBP = PAR ? L / NVB : NBE;                 // blocks of this parity
+    constexpr int BSTEP = NT / G;
+    cplx<T>* Tp = Tb + ((size_t)(PAR ? NBE : 0) * nx + i0 + rr) * NVB;
+    for (int b = bi; b < NBP; b += BSTEP) {
+        Blk<T, NVB> o;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const cplx<T>* rr = h ? r1 : r0;
-            const cplx<T> zv = rr[F::pad(ia)];
-            const cplx<T> zm = conj(rr[F::pad(ib)]);
-            o[h] = T(0.5) * ((zv + zm) + mul_mi(w * (zv - zm)));
+        for (int h = 0; h < NVB; ++h) {
+            const int m = NVB * b + h;
+            const bool valid = PAR || m <= L;
+            const int ia = PAR ? m : (m >= L ? 0 : m);
+            const int ib = PAR ? (L - 1 - m) : ((m == 0 || m > L) ? 0 : L - m);
+            const cplx<T> w = twQ[valid ? 2 * m + PAR : 0];
+            const cplx<T> zv = zr[F::pad(ia)];
+            const cplx<T> zm = conj(zr[F::pad(ib)]);
+            o.c[h] = T(0.5) * ((zv + zm) + mul_mi(w * (zv - zm)));
+            if (!valid) o.c[h] = cplx<T>(0, 0);
         }
-        // rows (i0 + 2rp, i0 + 2rp + 1) of column v: 16 contiguous bytes (fp32)
-        store2<T>(Tb + (size_t)v * nx + i0 + 2 * rp, o[0], o[1]);
+        storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
     }
     // the next FFT's first exchange starts with a barrier, protecting these LDS reads
 }
@@ -253,17 +436,19 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
     constexpr int G = row_groups<T, L, E>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
-    constexpr int HP = G / 2;
-    constexpr int MSTEP = NT / HP;
-    const int rp = threadIdx.x % HP, mi = threadIdx.x / HP;
-    cplx<T>* w0 = lds0 + (size_t)(2 * rp) * STRIDE;
-    cplx<T>* w1 = w0 + STRIDE;
+    const int rr = threadIdx.x % G, bi = threadIdx.x / G;
+    cplx<T>* yr = lds0 + (size_t)rr * STRIDE;
     __syncthreads();                            // previous phase done with the LDS
-    constexpr int mend = PAR ? L : L + 1;
-    for (int m = mi; m < mend; m += MSTEP) {
-        const Pair2<T> y2 = load2<T>(Tb + (size_t)(2 * m + PAR) * nx + i0 + 2 * rp);
-        w0[F::pad(m)] = y2.a;
-        w1[F::pad(m)] = y2.b;
+    constexpr int NVB = FastCfg<T>::NVB;
+    constexpr int NBE = (L + NVB) / NVB;
+    constexpr int NBP = PAR ? L / NVB : NBE;
+    constexpr int BSTEP = NT / G;
+    const cplx<T>* Tp = Tb + ((size_t)(PAR ? NBE : 0) * nx + i0 + rr) * NVB;
+    for (int b = bi; b < NBP; b += BSTEP) {
+        const Blk<T, NVB> y = loadb<T, NVB>(Tp + (size_t)b * nx * NVB);   // bins of block b, row rr
+#pragma unroll
+        for (int h = 0; h < NVB; ++h)
+            if (PAR || NVB * b + h <= L) yr[F::pad(NVB * b + h)] = y.c[h];
     }
     __syncthreads();
     // Z[v] = (Y[v] + conj Y[M-v]) + i conj(w_Q^v) (Y[v] - conj Y[M-v]),  v = 2m + PAR
@@ -346,6 +531,8 @@ struct FastTables {            // device tables owned by the plan (stored behind
     void* ptw_col;
     void* ptw_row;
     void* twM;                 // exp(-2 pi i n / M), n < L
+    int col_persistent;        // PFB_COL_PERSIST (default 0): persistent prefetching column kernel
+    int num_cu;
 };
 
 template <typename T, int N, int E>
@@ -372,6 +559,8 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     switch (H) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, FastCfg<T>::ECOL>(&ft->ptw_col);                          \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2<T, NN, FastCfg<T>::ECOL>, \
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2p<T, NN, FastCfg<T>::ECOL>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -424,10 +613,24 @@ int pow2_rows_per_wg(const pfb_conv_plan* p) {
     }
 }
 
+int pow2_nblocks(const pfb_conv_plan* p) {
+    return fast_nblocks(p->ny / 2, p->dtype == PFB_F32 ? FastCfg<float>::NVB : FastCfg<double>::NVB);
+}
+int pow2_nvb(const pfb_conv_plan* p) {
+    return p->dtype == PFB_F32 ? FastCfg<float>::NVB : FastCfg<double>::NVB;
+}
+
 int pow2_prepare(pfb_conv_plan* p) {
     FastTables* ft = (FastTables*)calloc(1, sizeof(FastTables));
     PFB_REQUIRE(ft != nullptr, PFB_ERR_ALLOC, "pow2_prepare: host alloc failed");
     p->fast_tables = ft;
+    ft->col_persistent = 0;   // measured slower than 2 WG/CU of the plain kernel (0.32 vs 0.24 ms at 4096^2): kept for A/B
+    if (const char* e = getenv("PFB_COL_PERSIST")) ft->col_persistent = atoi(e) ? 1 : 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        ft->num_cu = prop.multiProcessorCount;
+    if (ft->num_cu <= 0) ft->num_cu = 256;
     return p->dtype == PFB_F32 ? prep_tables<float>(p, ft) : prep_tables<double>(p, ft);
 }
 
@@ -444,9 +647,11 @@ void pow2_release(pfb_conv_plan* p) {
 template <typename T>
 static int set_psfhat_t(pfb_conv_plan* p, const void* psfhat, hipStream_t st) {
     const int nv = p->M + 1;
+    // the dummy partner of the last even bin (and nothing else) is never written: zero all
+    PFB_HIP_CHECK(hipMemsetAsync(p->psf_l, 0, sizeof(cplx<T>) * p->psf_elems_per_band * p->nband, st));
     dim3 grid((nv + 31) / 32, (p->P + 31) / 32, p->nband);
     hipLaunchKernelGGL((k_relayout_psf_pow2<T>), grid, dim3(256), 0, st, (const cplx<T>*)psfhat,
-                       (cplx<T>*)p->psf_l, p->P, nv, p->psf_elems_per_band);
+                       (cplx<T>*)p->psf_l, p->P, nv, p->ny / 2, FastCfg<T>::NVB, p->psf_elems_per_band);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
@@ -460,11 +665,24 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
     constexpr int E = FastCfg<T>::ECOL;
     using F = RegFft<T, H, E>;
     constexpr int GC = col_groups<H, E>();
-    const int nv = p->M + 1;
-    const size_t lds = sizeof(cplx<T>) * (size_t)GC * F::LDS_ELEMS;
-    hipLaunchKernelGGL((k_col_pow2<T, H, E>), dim3((nv + GC - 1) / GC, nb), dim3(GC * F::TPB), lds, st,
+    const int nblk = fast_nblocks(p->ny / 2, FastCfg<T>::NVB);
+    const size_t lds = sizeof(cplx<T>) * (size_t)GC * FastCfg<T>::NVB * F::LDS_ELEMS;
+    if (ft->col_persistent) {
+        // one resident workgroup set: 8 waves per CU at 256 VGPRs
+        const int nitems = nblk * nb;
+        const int wg_per_cu = (8 * 64) / (GC * F::TPB) > 0 ? (8 * 64) / (GC * F::TPB) : 1;
+        int grid = ft->num_cu * wg_per_cu;
+        const int need = (nitems + GC - 1) / GC;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL((k_col_pow2p<T, H, E>), dim3(grid), dim3(GC * F::TPB), lds, st,
+                           (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
+                           (const cplx<T>*)ft->ptw_col, nblk, nitems, p->T_elems_per_band,
+                           p->psf_elems_per_band, band0);
+        return;
+    }
+    hipLaunchKernelGGL((k_col_pow2<T, H, E>), dim3((nblk + GC - 1) / GC, nb), dim3(GC * F::TPB), lds, st,
                        (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
-                       (const cplx<T>*)ft->ptw_col, nv, p->T_elems_per_band, p->psf_elems_per_band, band0);
+                       (const cplx<T>*)ft->ptw_col, nblk, p->T_elems_per_band, p->psf_elems_per_band, band0);
 }
 
 template <typename T, int L>
