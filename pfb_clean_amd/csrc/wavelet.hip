@@ -1,14 +1,588 @@
-// wavelet.hip -- psi / prox / primal-dual kernels (entry points stubbed until they land).
+// wavelet.hip -- psi / psi^H (multi-level separable Daubechies DWT, zero-extension mode),
+// the l21 dual update / prox and the primal-dual image update.
+//
+// Replaces the numba loops of pfb/wavelets/wavelets.py:127-315 (dwt2d_level / idwt2d_level
+// + copyT), pfb/operators/psi.py:187-256 (psi_band.dot / hdot), pfb/prox/prox_21m.py:31-103
+// and the numexpr passes of pfb/opt/primal_dual.py:137-146.
+//
+// One fused kernel per decomposition level: a workgroup stages an input tile (with its
+// F-tap halo) in LDS, runs BOTH 1-D passes on chip and writes each output once, already
+// in the reference's transposed (y-major) packed coefficient layout -- the reference's
+// separate row pass, copyT transpose and column pass (3 sweeps over HBM) become one.
+// All memory-bound: coalesced row reads, LDS-staged taps, no MFMA (no contraction).
+//
+//   analysis 1-D :  out[o]   = sum_{j<F} filt[j] in[2o+1-j]          (zero outside)
+//   synthesis 1-D:  out[2m+p] = sum_{j<F/2} lo[2j+p] a[m+h-1-j] + sum_j hi[2j+p] d[m+h-1-j]
+//                   m = 0 .. N-h,  h = F/2                           (wavelets.py:99-123)
 #include "common.hpp"
-using namespace pfb;
-extern "C" {
-#define PFB_TODO(name) set_error(name ": not implemented yet"); return PFB_ERR_UNSUPPORTED
-int pfb_psi_plan_create(int, int, int, int, const int*, const double*, int, int, pfb_psi_plan**) { PFB_TODO("pfb_psi_plan_create"); }
-int pfb_psi_plan_destroy(pfb_psi_plan*) { return PFB_OK; }
-int pfb_psi_plan_dims(const pfb_psi_plan*, int*, int*) { PFB_TODO("pfb_psi_plan_dims"); }
-int pfb_psi_dot(pfb_psi_plan*, const void*, void*, void*) { PFB_TODO("pfb_psi_dot"); }
-int pfb_psi_hdot(pfb_psi_plan*, const void*, void*, void*) { PFB_TODO("pfb_psi_hdot"); }
-int pfb_dual_update(int, const void*, void*, const void*, double, double, int, size_t, void*, void*) { PFB_TODO("pfb_dual_update"); }
-int pfb_prox_21m(int, const void*, void*, const void*, double, double, int, size_t, void*) { PFB_TODO("pfb_prox_21m"); }
-int pfb_pd_primal_update(int, const void*, const void*, const void*, double, int, int, size_t, void*, double*, double*, void*) { PFB_TODO("pfb_pd_primal_update"); }
+#include <vector>
+#include <cstring>
+
+namespace pfb {
+
+constexpr int MAXF = 18;        // db9
+constexpr int MAXLEV = 12;
+constexpr int TA = 16;          // analysis: output tile edge (coefficients per quadrant)
+constexpr int TS = 32;          // synthesis: output tile edge (image pixels)
+
+template <typename T> struct Filt { T lo[MAXF]; T hi[MAXF]; int F; };
+
+struct LevelInfo {
+    int nxin, nyin;     // analysis input (= approx of the previous level) shape
+    int Cx, Cy;         // coefficients per half at this level (sx, sy)
+    int lowx, lowy;     // origin of this level's (2Cy, 2Cx) block in the packed plane
+    int nxo, nyo;       // synthesis output shape (spx, spy)
+};
+
+struct BasisInfo {
+    int K, F, Ntotx, Ntoty;
+    LevelInfo lev[MAXLEV];
+    double filt[4][MAXF];       // dec_lo, dec_hi, rec_lo, rec_hi
+};
+
+}  // namespace pfb
+
+struct pfb_psi_plan {
+    int nband, nx, ny, nbasis, nlevel, dtype;
+    int Nxmax, Nymax;
+    pfb::BasisInfo* bases;
+    void* scratch[2];           // per band ping-pong approx / partial-image buffers
+    size_t scratch_band;        // elements per band in each scratch buffer
+};
+
+namespace pfb {
+
+static inline int coeff_size(int n, int F) { return (n + F - 1) / 2; }
+static inline int signal_size(int c, int F) { return 2 * c - F + 2; }
+
+// ------------------------------------------------------------------ 'self' basis
+// dst[c][r] = src[r][c]   (src R x C, ld ls; dst ld ld); ACC adds instead of storing
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256)
+k_transpose(const T* __restrict__ src, size_t src_band, int ls, T* __restrict__ dst, size_t dst_band,
+            int ld, int R, int C) {
+    __shared__ T tile[32][33];
+    const T* s = src + (size_t)blockIdx.z * src_band;
+    T* d = dst + (size_t)blockIdx.z * dst_band;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < R && c0 + tx < C) tile[r][tx] = s[(size_t)(r0 + r) * ls + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < C && r0 + tx < R) {
+            T* p = d + (size_t)(c0 + c) * ld + r0 + tx;
+            if (ACC) *p += tile[tx][c]; else *p = tile[tx][c];
+        }
 }
+
+// ------------------------------------------------------------------ analysis level
+// in    : (nxin, nyin) row-major, ld = ldin
+// coeffs: this level's block origin, ld = ldc; quadrants [0:Cy | Cy:2Cy] x [0:Cx | Cx:2Cx]
+// approx: optional (Cx, Cy) row-major copy of the LL quadrant transposed (next level input)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int nyin,
+            T* __restrict__ coeffs, size_t c_band, int ldc, int Cx, int Cy,
+            T* __restrict__ approx, size_t a_band, Filt<T> f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = f.F;
+    const int NI = 2 * TA + F - 2;            // input samples per tile edge
+    const int SA = NI + 1;                    // LDS strides (odd -> conflict-free columns)
+    const int SB = 2 * TA + 1;
+    T* A = reinterpret_cast<T*>(smem);        // [NI][SA]   input tile  A[lx][ly]
+    T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
+    T* LL = B + NI * SB;                      // [TA][TA+1] LL quadrant for the approx copy
+    const T* src = in + (size_t)blockIdx.z * in_band;
+    T* dst = coeffs + (size_t)blockIdx.z * c_band;
+    const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
+    const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
+    // 1. stage the input tile (zero extension outside the signal)
+    for (int e = threadIdx.x; e < NI * NI; e += blockDim.x) {
+        const int lx = e / NI, ly = e - lx * NI;
+        const int gx = gx0 + lx, gy = gy0 + ly;
+        T v = 0;
+        if (gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
+        A[lx * SA + ly] = v;
+    }
+    __syncthreads();
+    // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
+    for (int e = threadIdx.x; e < NI * 2 * TA; e += blockDim.x) {
+        const int lx = e / (2 * TA), q = e - lx * (2 * TA);
+        const bool hi = q >= TA;
+        const int qq = hi ? q - TA : q;
+        const T* flt = hi ? f.hi : f.lo;
+        const T* a = A + lx * SA + 2 * qq + F - 1;
+        T s = 0;
+        for (int j = 0; j < F; ++j) s += flt[j] * a[-j];
+        B[lx * SB + q] = s;
+    }
+    __syncthreads();
+    // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c < 2TA (x coefficient)
+    for (int e = threadIdx.x; e < 2 * TA * 2 * TA; e += blockDim.x) {
+        const int r = e / (2 * TA), c = e - r * (2 * TA);
+        const bool hix = c >= TA;
+        const int cc = hix ? c - TA : c;
+        const T* flt = hix ? f.hi : f.lo;
+        const T* b = B + (2 * cc + F - 1) * SB + r;
+        T s = 0;
+        for (int j = 0; j < F; ++j) s += flt[j] * b[-j * SB];
+        const bool hiy = r >= TA;
+        const int rr = hiy ? r - TA : r;
+        const int gy = oy0 + rr, gx = ox0 + cc;
+        if (gy < Cy && gx < Cx)
+            dst[(size_t)((hiy ? Cy : 0) + gy) * ldc + (hix ? Cx : 0) + gx] = s;
+        if (!hiy && !hix) LL[cc * (TA + 1) + rr] = s;
+    }
+    if (approx) {
+        __syncthreads();
+        T* ap = approx + (size_t)blockIdx.z * a_band;
+        for (int e = threadIdx.x; e < TA * TA; e += blockDim.x) {
+            const int cc = e / TA, rr = e - cc * TA;           // rr (y) fastest: coalesced
+            if (ox0 + cc < Cx && oy0 + rr < Cy) ap[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
+        }
+    }
+}
+
+// ----------------------------------------------------------------- synthesis level
+// coeffs : this level's (2 nay, 2 nax) block, ld = ldc (y-major)
+// prev   : if non-null, the approx quadrant is prev[c][r] (previous level's image,
+//          row-major ld = ldp) instead of coeffs[r][c]      (wavelets.py:303-309)
+// out    : image (nxw, nyw) row-major ld = ldo; ACC adds (sum over bases, psi.py:252)
+template <typename T, bool ACC>
+__global__ void __launch_bounds__(256)
+k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int nay,
+             const T* __restrict__ prev, size_t p_band, int ldp,
+             T* __restrict__ out, size_t o_band, int ldo, int nxw, int nyw, Filt<T> f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = f.F, h = F / 2;
+    const int NC = TS / 2 + h - 1;            // coefficients needed per half and tile edge
+    const int SC = 2 * NC + 1;
+    const int ST = TS + 1;
+    T* C = reinterpret_cast<T*>(smem);        // [2NC][SC]  C[ry][cx]  (lo|hi in both)
+    T* Tm = C + 2 * NC * SC;                  // [2NC][ST]  after the x pass  Tm[ry][ox]
+    const T* src = coeffs + (size_t)blockIdx.z * c_band;
+    const T* pv = prev ? prev + (size_t)blockIdx.z * p_band : nullptr;
+    T* dst = out + (size_t)blockIdx.z * o_band;
+    const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
+    const int mx0 = ix0 / 2, my0 = iy0 / 2;
+    // 1. stage coefficients; rows/cols beyond (nay, nax) are only used by cropped outputs
+    for (int e = threadIdx.x; e < 2 * NC * 2 * NC; e += blockDim.x) {
+        int ry, cx;
+        if (pv) { cx = e / (2 * NC); ry = e - cx * (2 * NC); }      // ry fastest: prev is read along y
+        else    { ry = e / (2 * NC); cx = e - ry * (2 * NC); }
+        const bool hy = ry >= NC, hx = cx >= NC;
+        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
+        T v = 0;
+        if (gy < nay && gx < nax) {
+            if (pv && !hy && !hx) v = pv[(size_t)gx * ldp + gy];
+            else v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+        }
+        C[ry * SC + cx] = v;
+    }
+    __syncthreads();
+    // 2. x pass: Tm[ry][ox] = sum_j lo[2j+p] C[ry][m+h-1-j] + sum_j hi[2j+p] C[ry][NC+m+h-1-j]
+    for (int e = threadIdx.x; e < 2 * NC * TS; e += blockDim.x) {
+        const int ry = e / TS, ox = e - ry * TS;
+        const int m = ox >> 1, p = ox & 1;
+        const T* c = C + ry * SC + m + h - 1;
+        T sl = 0, sh = 0;
+        for (int j = 0; j < h; ++j) { sl += f.lo[2 * j + p] * c[-j]; sh += f.hi[2 * j + p] * c[NC - j]; }
+        Tm[ry * ST + ox] = sl + sh;
+    }
+    __syncthreads();
+    // 3. y pass + store (iy fastest)
+    for (int e = threadIdx.x; e < TS * TS; e += blockDim.x) {
+        const int ox = e / TS, oy = e - ox * TS;
+        const int m = oy >> 1, p = oy & 1;
+        const T* t = Tm + (m + h - 1) * ST + ox;
+        T sl = 0, sh = 0;
+        for (int j = 0; j < h; ++j) { sl += f.lo[2 * j + p] * t[-j * ST]; sh += f.hi[2 * j + p] * t[(NC - j) * ST]; }
+        const int gx = ix0 + ox, gy = iy0 + oy;
+        if (gx < nxw && gy < nyw) {
+            T* q = dst + (size_t)gx * ldo + gy;
+            if (ACC) *q += sl + sh; else *q = sl + sh;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_fill(T* p, size_t n, T v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// --------------------------------------------------------------------- prox / PD
+// dual_update_numba (prox_21m.py:76-103): vt = vp + sigma v; a = |sum_band vt / sigma|;
+// v = vt * (a != 0 ? 1 - max(a - lam w / sigma, 0)/a : 1);  optionally vp_out = 2 v - vp
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dual_update(const T* vp, T* __restrict__ v, const T* __restrict__ w, T lam, T sigma,
+              int nband, size_t nper, T* vp_out) {        // vp_out may alias vp
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
+         i += (size_t)gridDim.x * blockDim.x) {
+        T sum = 0;
+        for (int b = 0; b < nband; ++b) sum += vp[(size_t)b * nper + i] + sigma * v[(size_t)b * nper + i];
+        const T a = fabs(sum / sigma);
+        T fac = 1;
+        if (a != T(0)) {
+            const T soft = fmax(a - lam * w[i] / sigma, T(0));
+            fac = T(1) - soft / a;
+        }
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * nper + i;
+            const T vpk = vp[k];
+            const T vt = vpk + sigma * v[k];
+            const T vn = (a != T(0)) ? vt * fac : vt;
+            v[k] = vn;
+            if (vp_out) vp_out[k] = T(2) * vn - vpk;
+        }
+    }
+}
+
+// prox_21m_numba (prox_21m.py:31-61)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_prox_21m(const T* __restrict__ v, T* __restrict__ res, const T* __restrict__ w, T lam, T sigma,
+           int nband, size_t nper) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
+         i += (size_t)gridDim.x * blockDim.x) {
+        T sum = 0;
+        for (int b = 0; b < nband; ++b) sum += v[(size_t)b * nper + i];
+        const T t = sum / sigma;
+        if (t == T(0)) {
+            for (int b = 0; b < nband; ++b) res[(size_t)b * nper + i] = 0;
+            continue;
+        }
+        const T a = fabs(t);
+        const T soft = fmax(a - lam * w[i] / sigma, T(0));
+        for (int b = 0; b < nband; ++b) res[(size_t)b * nper + i] = v[(size_t)b * nper + i] * soft / a / sigma;
+    }
+}
+
+// x = xp - tau (xout + g) ; positivity ; norm_diff partials + any(x)   (primal_dual.py:139-150)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pd_primal(const T* __restrict__ xp, const T* __restrict__ xout, const T* __restrict__ g, T tau,
+            int positivity, int nband, size_t npix, T* __restrict__ x, double* __restrict__ ws) {
+    __shared__ double red[3 * 4];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (size_t)gridDim.x * blockDim.x) {
+        bool kill = false;
+        if (positivity == 2) {
+            for (int b = 0; b < nband; ++b) {
+                const size_t k = (size_t)b * npix + i;
+                const T gk = g ? g[k] : T(0);
+                const T val = xp[k] - tau * (xout[k] + gk);
+                if (val <= T(0)) kill = true;
+            }
+        }
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * npix + i;
+            const T gk = g ? g[k] : T(0);
+            T val = xp[k] - tau * (xout[k] + gk);
+            if (positivity == 1 && val < T(0)) val = 0;
+            if (kill) val = 0;
+            x[k] = val;
+            const double d = (double)val - (double)xp[k];
+            acc[0] += d * d;
+            acc[1] += (double)val * (double)val;
+            acc[2] += (val != T(0)) ? 1.0 : 0.0;
+        }
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 3; ++q) ws[(size_t)q * gridDim.x + blockIdx.x] = acc[q];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_final_sum3(const double* __restrict__ ws, int G, int nq, double* __restrict__ out) {
+    __shared__ double red[4];
+    for (int q = 0; q < nq; ++q) {
+        double acc[1] = {0.0};
+        for (int g = threadIdx.x; g < G; g += blockDim.x) acc[0] += ws[(size_t)q * G + g];
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) out[q] = acc[0];
+    }
+}
+
+// ------------------------------------------------------------------- host drivers
+template <typename T>
+static Filt<T> make_filt(const BasisInfo& b, int lo_idx, int hi_idx) {
+    Filt<T> f;
+    memset(&f, 0, sizeof(f));
+    f.F = b.F;
+    for (int k = 0; k < b.F; ++k) { f.lo[k] = (T)b.filt[lo_idx][k]; f.hi[k] = (T)b.filt[hi_idx][k]; }
+    return f;
+}
+
+template <typename T>
+static size_t dwt_lds(int F) {
+    const int NI = 2 * TA + F - 2;
+    return sizeof(T) * ((size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1) + (size_t)TA * (TA + 1));
+}
+template <typename T>
+static size_t idwt_lds(int F) {
+    const int NC = TS / 2 + F / 2 - 1;
+    return sizeof(T) * ((size_t)2 * NC * (2 * NC + 1) + (size_t)2 * NC * (TS + 1));
+}
+
+template <typename T>
+static int psi_dot_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st) {
+    const size_t plane = (size_t)p->Nymax * p->Nxmax;
+    const size_t aband = plane * p->nbasis;
+    const size_t xband = (size_t)p->nx * p->ny;
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        const BasisInfo& b = p->bases[ib];
+        T* ab = alpha + (size_t)ib * plane;
+        if (b.K == 0) {        // 'self': alpha[b, ib, 0:ny, 0:nx] = x[b].T     (psi.py:196-199)
+            dim3 grid((p->ny + 31) / 32, (p->nx + 31) / 32, p->nband);
+            hipLaunchKernelGGL((k_transpose<T, false>), grid, dim3(256), 0, st, x, xband, p->ny, ab, aband,
+                               p->Nxmax, p->nx, p->ny);
+            continue;
+        }
+        const Filt<T> f = make_filt<T>(b, 0, 1);
+        const T* in = x;
+        size_t in_band = xband;
+        int ldin = p->ny;
+        for (int l = 0; l < p->nlevel; ++l) {
+            const LevelInfo& L = b.lev[l];
+            T* blk = ab + (size_t)L.lowy * p->Nxmax + L.lowx;
+            const bool last = l == p->nlevel - 1;
+            T* approx = last ? nullptr : (T*)p->scratch[l & 1];
+            dim3 grid((L.Cx + TA - 1) / TA, (L.Cy + TA - 1) / TA, p->nband);
+            hipLaunchKernelGGL((k_dwt_level<T>), grid, dim3(256), dwt_lds<T>(b.F), st, in, in_band, ldin,
+                               L.nxin, L.nyin, blk, aband, p->Nxmax, L.Cx, L.Cy, approx, p->scratch_band, f);
+            in = approx;
+            in_band = p->scratch_band;
+            ldin = L.Cy;
+        }
+    }
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+template <typename T>
+static int psi_hdot_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
+    const size_t plane = (size_t)p->Nymax * p->Nxmax;
+    const size_t aband = plane * p->nbasis;
+    const size_t xband = (size_t)p->nx * p->ny;
+    bool first = true;          // first basis stores, the others accumulate (xo zeroed implicitly)
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        const BasisInfo& b = p->bases[ib];
+        const T* ab = alpha + (size_t)ib * plane;
+        if (b.K == 0) {        // xo[b] (+)= alpha[b, ib, 0:ny, 0:nx].T          (psi.py:229-232)
+            dim3 grid((p->nx + 31) / 32, (p->ny + 31) / 32, p->nband);
+            if (first)
+                hipLaunchKernelGGL((k_transpose<T, false>), grid, dim3(256), 0, st, ab, aband, p->Nxmax, xo,
+                                   xband, p->ny, p->ny, p->nx);
+            else
+                hipLaunchKernelGGL((k_transpose<T, true>), grid, dim3(256), 0, st, ab, aband, p->Nxmax, xo,
+                                   xband, p->ny, p->ny, p->nx);
+            first = false;
+            continue;
+        }
+        const Filt<T> f = make_filt<T>(b, 2, 3);
+        const T* prev = nullptr;
+        int ldp = 0;
+        for (int l = p->nlevel - 1; l >= 0; --l) {
+            const LevelInfo& L = b.lev[l];
+            const T* blk = ab + (size_t)L.lowy * p->Nxmax + L.lowx;
+            const bool finest = l == 0;
+            T* out = finest ? xo : (T*)p->scratch[l & 1];
+            const size_t o_band = finest ? xband : p->scratch_band;
+            const int nxw = finest ? (L.nxo < p->nx ? L.nxo : p->nx) : L.nxo;
+            const int nyw = finest ? (L.nyo < p->ny ? L.nyo : p->ny) : L.nyo;
+            const int ldo = finest ? p->ny : L.nyo;
+            dim3 grid((nxw + TS - 1) / TS, (nyw + TS - 1) / TS, p->nband);
+            if (finest && !first)
+                hipLaunchKernelGGL((k_idwt_level<T, true>), grid, dim3(256), idwt_lds<T>(b.F), st, blk, aband,
+                                   p->Nxmax, L.Cx, L.Cy, prev, p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
+            else
+                hipLaunchKernelGGL((k_idwt_level<T, false>), grid, dim3(256), idwt_lds<T>(b.F), st, blk, aband,
+                                   p->Nxmax, L.Cx, L.Cy, prev, p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
+            prev = out;
+            ldp = ldo;
+        }
+        // signal_size(Cx) can fall short of nx only if nx were odd and ... it cannot: the
+        // finest level always covers [0, nx) x [0, ny) (2 Cx - F + 2 >= nx)
+        first = false;
+    }
+    if (first) {               // no bases at all: xo = 0
+        hipLaunchKernelGGL((k_fill<T>), dim3(1024), dim3(256), 0, st, xo, xband * p->nband, (T)0);
+    }
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+static inline int ew_grid(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace pfb
+
+using namespace pfb;
+
+extern "C" {
+
+int pfb_psi_plan_create(int nband, int nx, int ny, int nbasis, const int* basis_k,
+                        const double* filters, int nlevel, int dtype, pfb_psi_plan** plan) {
+    PFB_REQUIRE(plan != nullptr, PFB_ERR_INVALID, "psi_plan_create: null plan pointer");
+    *plan = nullptr;
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "psi_plan_create: bad dtype");
+    PFB_REQUIRE(nband > 0 && nx > 0 && ny > 0 && nbasis > 0 && basis_k && filters, PFB_ERR_INVALID,
+                "psi_plan_create: bad argument");
+    PFB_REQUIRE(nlevel >= 1 && nlevel <= MAXLEV, PFB_ERR_UNSUPPORTED, "psi_plan_create: nlevel %d", nlevel);
+    pfb_psi_plan* p = (pfb_psi_plan*)calloc(1, sizeof(pfb_psi_plan));
+    PFB_REQUIRE(p != nullptr, PFB_ERR_ALLOC, "psi_plan_create: host alloc failed");
+    p->bases = (BasisInfo*)calloc(nbasis, sizeof(BasisInfo));
+    if (!p->bases) { free(p); set_error("psi_plan_create: host alloc failed"); return PFB_ERR_ALLOC; }
+    p->nband = nband; p->nx = nx; p->ny = ny; p->nbasis = nbasis; p->nlevel = nlevel; p->dtype = dtype;
+    size_t scratch_elems = 1;
+    for (int ib = 0; ib < nbasis; ++ib) {
+        BasisInfo& b = p->bases[ib];
+        b.K = basis_k[ib];
+        if (b.K == 0) continue;
+        if (b.K < 1 || b.K > 9) {
+            free(p->bases); free(p);
+            set_error("psi_plan_create: basis db%d unsupported (db1..db9)", basis_k[ib]);
+            return PFB_ERR_UNSUPPORTED;
+        }
+        b.F = 2 * b.K;
+        for (int q = 0; q < 4; ++q)
+            for (int k = 0; k < MAXF; ++k) b.filt[q][k] = filters[((size_t)ib * 4 + q) * MAXF + k];
+        // bookkeeping of pfb/operators/psi.py:49-94
+        int Nx = nx, Ny = ny, totx = 0, toty = 0;
+        int ainx = nx, ainy = ny;                 // actual analysis input shape per level
+        for (int l = 0; l < nlevel; ++l) {
+            LevelInfo& L = b.lev[l];
+            L.Cx = coeff_size(Nx, b.F);
+            L.Cy = coeff_size(Ny, b.F);
+            L.nxin = ainx; L.nyin = ainy;
+            totx += L.Cx; toty += L.Cy;
+            Nx = L.Cx + L.Cx % 2;
+            Ny = L.Cy + L.Cy % 2;
+            L.nxo = signal_size(L.Cx, b.F);
+            L.nyo = signal_size(L.Cy, b.F);
+            ainx = L.Cx; ainy = L.Cy;             // the approx passed on is (Cx, Cy), wavelets.py:171
+            // scratch holds the approx handed to the next analysis level (Cx*Cy, not for the
+            // last level) and the partial images of the synthesis (nxo*nyo, not for level 0)
+            if (l < nlevel - 1 && (size_t)L.Cx * L.Cy > scratch_elems) scratch_elems = (size_t)L.Cx * L.Cy;
+            if (l > 0 && (size_t)L.nxo * L.nyo > scratch_elems) scratch_elems = (size_t)L.nxo * L.nyo;
+        }
+        b.Ntotx = totx + b.lev[nlevel - 1].Cx;
+        b.Ntoty = toty + b.lev[nlevel - 1].Cy;
+        int highx = 2 * b.lev[nlevel - 1].Cx, highy = 2 * b.lev[nlevel - 1].Cy;
+        for (int l = nlevel - 1; l >= 0; --l) {
+            LevelInfo& L = b.lev[l];
+            if (l < nlevel - 1) { highx += L.Cx; highy += L.Cy; }
+            L.lowx = highx - 2 * L.Cx;
+            L.lowy = highy - 2 * L.Cy;
+        }
+        if (b.Ntotx > p->Nxmax) p->Nxmax = b.Ntotx;
+        if (b.Ntoty > p->Nymax) p->Nymax = b.Ntoty;
+    }
+    // 'self' only dictionaries: the reference leaves Nxmax = Nymax = 0 (psi.py:32-33,77-78)
+    // and cannot hold the image; we size the plane to the image so the operator stays usable
+    bool any_db = false;
+    for (int ib = 0; ib < nbasis; ++ib) any_db = any_db || p->bases[ib].K != 0;
+    if (!any_db) { p->Nxmax = nx; p->Nymax = ny; }
+    if (p->Nxmax < nx) p->Nxmax = nx;
+    if (p->Nymax < ny) p->Nymax = ny;
+    p->scratch_band = scratch_elems;
+    const size_t esz = dtype == PFB_F32 ? 4 : 8;
+    for (int k = 0; k < 2; ++k) {
+        if (hipMalloc(&p->scratch[k], esz * scratch_elems * nband) != hipSuccess) {
+            pfb_psi_plan_destroy(p);
+            set_error("psi_plan_create: device allocation failed");
+            return PFB_ERR_ALLOC;
+        }
+    }
+    const int lds_max = 160 * 1024;
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_dwt_level<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_dwt_level<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    *plan = p;
+    return PFB_OK;
+}
+
+int pfb_psi_plan_destroy(pfb_psi_plan* p) {
+    if (!p) return PFB_OK;
+    for (int k = 0; k < 2; ++k) if (p->scratch[k]) (void)hipFree(p->scratch[k]);
+    free(p->bases);
+    free(p);
+    return PFB_OK;
+}
+
+int pfb_psi_plan_dims(const pfb_psi_plan* p, int* nymax, int* nxmax) {
+    PFB_REQUIRE(p != nullptr, PFB_ERR_INVALID, "psi_plan_dims: null plan");
+    if (nymax) *nymax = p->Nymax;
+    if (nxmax) *nxmax = p->Nxmax;
+    return PFB_OK;
+}
+
+int pfb_psi_dot(pfb_psi_plan* p, const void* x, void* alpha, void* stream) {
+    PFB_REQUIRE(p && x && alpha, PFB_ERR_INVALID, "psi_dot: null argument");
+    return p->dtype == PFB_F32 ? psi_dot_t<float>(p, (const float*)x, (float*)alpha, as_stream(stream))
+                               : psi_dot_t<double>(p, (const double*)x, (double*)alpha, as_stream(stream));
+}
+
+int pfb_psi_hdot(pfb_psi_plan* p, const void* alpha, void* xo, void* stream) {
+    PFB_REQUIRE(p && alpha && xo, PFB_ERR_INVALID, "psi_hdot: null argument");
+    return p->dtype == PFB_F32 ? psi_hdot_t<float>(p, (const float*)alpha, (float*)xo, as_stream(stream))
+                               : psi_hdot_t<double>(p, (const double*)alpha, (double*)xo, as_stream(stream));
+}
+
+int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight, double lam, double sigma,
+                    int nband, size_t nper, void* vp_out, void* stream) {
+    PFB_REQUIRE(vp && v && weight && nband > 0, PFB_ERR_INVALID, "dual_update: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_dual_update<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
+                           (float*)v, (const float*)weight, (float)lam, (float)sigma, nband, nper, (float*)vp_out);
+    else
+        hipLaunchKernelGGL((k_dual_update<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
+                           (double*)v, (const double*)weight, lam, sigma, nband, nper, (double*)vp_out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight, double lam, double sigma,
+                 int nband, size_t nper, void* stream) {
+    PFB_REQUIRE(v && result && weight && nband > 0, PFB_ERR_INVALID, "prox_21m: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_prox_21m<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)v,
+                           (float*)result, (const float*)weight, (float)lam, (float)sigma, nband, nper);
+    else
+        hipLaunchKernelGGL((k_prox_21m<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)v,
+                           (double*)result, (const double*)weight, lam, sigma, nband, nper);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void* g, double tau,
+                         int positivity, int nband, size_t npix, void* x, double* sums, double* ws,
+                         void* stream) {
+    PFB_REQUIRE(xp && xout && x && sums && ws && nband > 0, PFB_ERR_INVALID, "pd_primal_update: bad argument");
+    hipStream_t st = as_stream(stream);
+    const int G = ew_grid(npix) > 1024 ? 1024 : ew_grid(npix);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_pd_primal<float>), dim3(G), dim3(256), 0, st, (const float*)xp, (const float*)xout,
+                           (const float*)g, (float)tau, positivity, nband, npix, (float*)x, ws);
+    else
+        hipLaunchKernelGGL((k_pd_primal<double>), dim3(G), dim3(256), 0, st, (const double*)xp,
+                           (const double*)xout, (const double*)g, tau, positivity, nband, npix, (double*)x, ws);
+    hipLaunchKernelGGL(k_final_sum3, dim3(1), dim3(256), 0, st, ws, G, 3, sums);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""
+Primal-dual (Condat-Vu) backward step on MI355X -- drop-in for
+pfb/opt/primal_dual.py:91-180 (primal_dual_optimised).
+
+Per iteration (reference statement -> device work):
+    psi(xp, v)                         pfb_psi_dot        (analysis, all bands/bases)
+    dual_update_numba(vp, v, ...)      pfb_dual_update    (fused with vp = 2 v - vp)
+    psiH(vp, xout)                     pfb_psi_hdot       (synthesis)
+    xout += grad(xp)                   caller's callable (one PSF convolution)
+    x = xp - tau xout ; positivity     pfb_pd_primal_update (+ norm_diff sums + any(x))
+    eps = norm_diff(x, xp)             from the same kernel's sums
+Everything stays on the GPU; two scalars per iteration come back for the stopping rule.
+
+Naming trap kept from the reference: the 4th positional `psiH` receives the SYNTHESIS
+operator (Psi.hdot), the 5th `psi` the ANALYSIS operator (Psi.dot) at the call site
+(workers/spotless.py:268-269); `prox` is accepted and unused.  Like the reference the
+iteration updates `x` and `v` IN PLACE and returns them.  Where the reference drops into
+pdb (x all zero, NaN eps) this returns with the state as is and a warning.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+
+from .. import _lib, _dev
+from ..prox.prox_21m import dual_update_numba
+
+
+def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, grad,
+                          nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000, positivity=1,
+                          report_freq=10, gamma=1.0, verbosity=1, maxreweight=50):
+    lib = _lib.load()
+    as_numpy = _dev.is_numpy(x)
+    xd = _dev.to_dev(x).contiguous()
+    vd = _dev.to_dev(v, xd.dtype).contiguous()
+    if as_numpy or xd is not x:
+        pass                                     # device copies; written back at the end
+    dt = xd.dtype
+    code = _dev.code(dt)
+    nband = xd.shape[0]
+    npix = xd[0].numel()
+    xp = xd.clone()
+    vp = vd.clone()
+    xout = torch.zeros_like(xd)
+    w = _dev.to_dev(l1weight, dt).contiguous()
+    ws, out = _dev.scratch()
+
+    if sigma is None:
+        sigma = L / (2.0 * gamma) / nu
+    tau = 0.9 / (L / (2.0 * gamma) + sigma * nu ** 2)
+
+    def host(t):
+        return t.cpu().numpy() if as_numpy else t
+
+    eps = 1.0
+    numreweight = 0
+    k = 0
+    for k in range(maxit):
+        psi(xp, vd)                                                      # :135
+        dual_update_numba(vp, vd, lam, sigma=sigma, weight=w, vp_out=vp)  # :136-137
+        psiH(vp, xout)                                                   # :138
+        g = grad(host(xp))                                               # :139
+        gd = _dev.to_dev(g, dt).contiguous()
+        _lib.check(lib.pfb_pd_primal_update(code, _dev.ptr(xp), _dev.ptr(xout), _dev.ptr(gd),
+                                            float(tau), int(positivity), nband, npix,
+                                            _dev.ptr(xd), _dev.ptr(out), _dev.ptr(ws),
+                                            _dev.stream()))              # :140-146
+        num, den, anyx = out[:3].tolist()
+        if anyx:
+            eps = math.sqrt(num / (1e-12 + den))
+        else:
+            print("primal_dual: x is identically zero (the reference stops in pdb here)",
+                  file=sys.stderr)
+            eps = 1.0
+        if eps < tol:
+            if reweighter is not None and numreweight < maxreweight:
+                w = _dev.to_dev(reweighter(host(xd)), dt).contiguous()
+                numreweight += 1
+            else:
+                if numreweight >= maxreweight and verbosity:
+                    print("Maximum reweighting steps reached", file=sys.stderr)
+                break
+        xp.copy_(xd)
+        vp.copy_(vd)
+        if math.isnan(eps) or math.isinf(eps):
+            print("primal_dual: non-finite eps (the reference stops in pdb here)", file=sys.stderr)
+            break
+        if not k % report_freq and verbosity > 1:
+            print(f"At iteration {k} eps = {eps:.3e}", file=sys.stderr)
+
+    if verbosity:
+        if k == maxit - 1:
+            print(f"Max iters reached. eps = {eps:.3e}", file=sys.stderr)
+        else:
+            print(f"Success, converged after {k} iterations", file=sys.stderr)
+
+    if as_numpy:
+        x[...] = xd.cpu().numpy()
+        v[...] = vd.cpu().numpy()
+        return x, v
+    if xd is not x:
+        x.copy_(xd)
+    if vd is not v:
+        v.copy_(vd)
+    return x, v

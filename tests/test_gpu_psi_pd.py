@@ -1,0 +1,245 @@
+"""
+GPU parity tests for the wavelet dictionary (psi / psi^H), the l21 prox / dual update and
+the primal-dual backward step, against golden vectors from the reference source
+(tests/golden/{psi,prox,pd}.npz) and the CPU oracle.  Mirrors the reference's own
+tests/test_psi_operator.py and tests/test_wavelets.py.
+
+Tolerances: fp64 1e-12 (psi coefficients vs reference: 1e-13 observed), fp32 1e-5.
+"""
+from functools import partial
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import wavelets as owv          # noqa: E402  (checker only)
+from oracle import prox as opx              # noqa: E402
+from oracle import solvers as osv           # noqa: E402
+from oracle import fftconv as ofc           # noqa: E402
+
+pmp = pytest.mark.parametrize
+
+
+@pytest.fixture(scope='module')
+def amd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.psi import Psi
+    from pfb_clean_amd.operators import psf
+    from pfb_clean_amd.prox import prox_21m, prox_21
+    from pfb_clean_amd.opt import primal_dual, power_method
+    from pfb_clean_amd.utils import misc
+
+    class NS:
+        pass
+    ns = NS()
+    ns.Psi, ns.psf, ns.p21m, ns.p21, ns.pd, ns.pm, ns.misc = Psi, psf, prox_21m, prox_21, primal_dual, power_method, misc
+    return ns
+
+
+def maxerr(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max()
+
+
+@pmp('rdt', [np.float64, np.float32])
+def test_psi_matches_reference_golden(amd, golden, rdt):
+    g = golden('psi')
+    tol = 1e-12 if rdt == np.float64 else 2e-5
+    for c in range(int(g['ncases'])):
+        nband, nx, ny, nlevel, Nymax, Nxmax = (int(v) for v in g[f'p{c}_meta'])
+        bases = [str(s) for s in g[f'p{c}_bases']]
+        psi = amd.Psi(nband, nx, ny, bases, nlevel, 1)
+        assert (psi.Nymax, psi.Nxmax, psi.nbasis) == (Nymax, Nxmax, len(bases))
+        ref = g[f'p{c}_alpha']
+        # sentinel-filled output: cells the reference never writes must stay untouched
+        alpha = np.full(ref.shape, 7.25, dtype=rdt)
+        psi.dot(g[f'p{c}_x'].astype(rdt), alpha)
+        written = ~np.isnan(ref)
+        assert np.all(alpha[~written] == 7.25), c
+        scale = np.abs(ref[written]).max()
+        assert maxerr(alpha[written], ref[written]) < tol * scale, c
+        xrec = np.full((nband, nx, ny), -3.5, dtype=rdt)
+        psi.hdot(g[f'p{c}_coef_in'].astype(rdt), xrec)
+        rr = g[f'p{c}_xrec']
+        assert maxerr(xrec, rr) < tol * np.abs(rr).max(), c
+
+
+@pmp("nx", [128, 250])
+@pmp("ny", [64, 78])
+@pmp("nband", [1, 3, 6])
+@pmp("nlevels", [1, 2])
+def test_psi(amd, nx, ny, nband, nlevels):
+    """reference tests/test_psi_operator.py:14-48: hdot(dot(x)) == nbasis * x to 1e-12 with
+    randomly populated outputs."""
+    np.random.seed(420)
+    image = np.random.randn(nx, ny)
+    nu = 1.0 + 0.1 * np.arange(nband)
+    x = image[None, 0:nx, 0:ny] * nu[:, None, None] ** (-0.7)
+    bases = ['self', 'db1', 'db2', 'db3', 'db4', 'db5']
+    nbasis = len(bases)
+    psi = amd.Psi(nband, nx, ny, bases, nlevels, 1)
+    alpha = np.random.randn(nband, nbasis, psi.Nymax, psi.Nxmax)
+    xrec = np.random.randn(nband, nx, ny)
+    psi.dot(x, alpha)
+    psi.hdot(alpha, xrec)
+    np.testing.assert_array_almost_equal(nbasis * x, xrec, decimal=12)
+
+
+@pmp("wavelet", ["db1", "db4", "db5", "db9"])
+@pmp("shape", [(128, 256), (512, 128)])
+@pmp("nlevel", [1, 2, 3])
+def test_dwt_idwt_roundtrip_and_layout(amd, wavelet, shape, nlevel):
+    """reference tests/test_wavelets.py:11-109: reconstruction + packed layout (the
+    layout is checked against the oracle, itself pinned to the reference)."""
+    rng = np.random.default_rng(5)
+    nx, ny = shape
+    data = rng.random((1, nx, ny))
+    from pfb_clean_amd.wavelets import dwt_max_level
+    if nlevel > dwt_max_level(min(nx, ny), wavelet):
+        with pytest.raises(ValueError):
+            amd.Psi(1, nx, ny, [wavelet], nlevel, 1)
+        return
+    psi = amd.Psi(1, nx, ny, [wavelet], nlevel, 1)
+    ref = owv.Psi(1, nx, ny, [wavelet], nlevel, 1)
+    assert (psi.Nymax, psi.Nxmax) == (ref.Nymax, ref.Nxmax)
+    a = np.zeros((1, 1, psi.Nymax, psi.Nxmax))
+    b = np.zeros_like(a)
+    psi.dot(data, a)
+    ref.dot(data, b)
+    assert maxerr(a, b) < 1e-13
+    rec = np.zeros_like(data)
+    psi.hdot(a, rec)
+    assert maxerr(rec, data) < 1e-12
+
+
+def test_psi_device_tensors_adjoint_and_errors(amd):
+    rng = np.random.default_rng(9)
+    nband, nx, ny = 2, 96, 80
+    bases = ['self', 'db2', 'db4']
+    psi = amd.Psi(nband, nx, ny, bases, 2, 1)
+    x = torch.from_numpy(rng.standard_normal((nband, nx, ny))).cuda()
+    a = torch.zeros((nband, 3, psi.Nymax, psi.Nxmax), dtype=torch.float64, device='cuda')
+    out = psi.dot(x, a)
+    assert out is a and a.is_cuda
+    mark = torch.full_like(a, float('nan'))
+    psi.dot(x, mark)
+    c = torch.from_numpy(rng.standard_normal(tuple(a.shape))).cuda()
+    c[torch.isnan(mark)] = 0.0
+    y = torch.empty_like(x)
+    psi.hdot(c, y)
+    lhs = torch.sum(a * c).item()
+    rhs = torch.sum(x * y).item()
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+    with pytest.raises(ValueError):
+        amd.Psi(1, 16, 16, ['db5'], 3, 1)
+    with pytest.raises(ValueError):
+        psi.dot(x[:1], a)
+
+
+@pmp('rdt', [np.float64, np.float32])
+def test_prox_golden(amd, golden, rdt):
+    g = golden('prox')
+    v, vp, w = g['v'].astype(rdt), g['vp'].astype(rdt), g['w'].astype(rdt)
+    rtol = 1e-12 if rdt == np.float64 else 2e-5
+    for i, (lam, sigma) in enumerate(g['grid']):
+        res = np.full(v.shape, np.nan, dtype=rdt)
+        amd.p21m.prox_21m_numba(v, res, lam, sigma=sigma, weight=w)
+        ref = g[f'g{i}_prox21m_numba']
+        assert maxerr(res, ref) <= rtol * max(np.abs(ref).max(), 1e-30), (i, 'prox')
+        vv = v.copy()
+        amd.p21m.dual_update_numba(vp, vv, lam, sigma=sigma, weight=w)
+        ref = g[f'g{i}_dual_update_numba']
+        assert maxerr(vv, ref) <= rtol * np.abs(ref).max(), (i, 'dual')
+        assert maxerr(amd.p21m.prox_21m(v, lam, weight=w), g[f'g{i}_prox21m']) <= rtol * 10
+        assert maxerr(amd.p21.prox_21(v, lam, weight=w), g[f'g{i}_prox21']) <= rtol * 10
+
+
+@pmp("nband", [1, 3, 6])
+@pmp("lam,sigma", [(1.0, 75.0), (1e-1, 1.0), (1e-3, 1e-3)])
+def test_dual_update_identity(amd, nband, lam, sigma):
+    """reference tests/test_psi_operator.py:150-193."""
+    rng = np.random.default_rng(11)
+    nx, ny = 120, 150
+    bases = ['self', 'db1', 'db2', 'db3', 'db4', 'db5']
+    psi = amd.Psi(nband, nx, ny, bases, 2, 1)
+    w = rng.random((len(bases), psi.Nymax, psi.Nxmax))
+    x = rng.standard_normal((nband, nx, ny))
+    v = np.zeros((nband, len(bases), psi.Nymax, psi.Nxmax))
+    psi.dot(rng.standard_normal(x.shape), v)
+    vp = v.copy()
+    res1 = amd.p21m.dual_update(v, x, psi.dot, lam, sigma=sigma, weight=w)
+    res_ref = opx.dual_update(vp.copy(), x, owv.Psi(nband, nx, ny, bases, 2, 1).dot, lam, sigma=sigma, weight=w)
+    psi.dot(x, v)
+    amd.p21m.dual_update_numba(vp, v, lam, sigma=sigma, weight=w)
+    np.testing.assert_array_almost_equal(1 + res_ref, 1 + v, decimal=9)
+    np.testing.assert_array_almost_equal(1 + res1, 1 + v, decimal=9)
+
+
+def test_primal_dual_trajectory_golden(amd, golden):
+    g = golden('pd')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx = ny = P // 2
+    bases = [str(s) for s in g['bases']]
+    psi = amd.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    data = g['data']
+    conv = partial(amd.psf.psf_convolve_cube, None, None, None, psfhat, Q)
+
+    def grad21(x):
+        return conv(x) - data
+    l1w = np.ones((len(bases), psi.Nymax, psi.Nxmax))
+    for tag, pos, maxit in (('pos1_it10', 1, 10), ('pos0_it4', 0, 4), ('pos2_it6', 2, 6)):
+        x0 = np.zeros((nb, nx, ny))
+        v0 = np.zeros((nb, len(bases), psi.Nymax, psi.Nxmax))
+        x, v = amd.pd.primal_dual_optimised(x0, v0, float(g['lam']), psi.hdot, psi.dot,
+                                            float(g['hessnorm']), None, l1w, None, grad21,
+                                            nu=len(bases), tol=0.0, maxit=maxit, positivity=pos,
+                                            verbosity=0)
+        assert x is x0 and v is v0                       # in place, like the reference
+        assert maxerr(x, g[f'{tag}_x']) < 1e-9 * max(np.abs(g[f'{tag}_x']).max(), 1e-30), tag
+        assert maxerr(v, g[f'{tag}_v']) < 1e-9 * np.abs(g[f'{tag}_v']).max(), tag
+
+
+def test_primal_dual_device_resident_with_reweighting(amd, golden):
+    """Tensor-in/tensor-out run with an l1 reweighter (spotless.py:243-285 wiring) against
+    the oracle's primal_dual_optimised on the same inputs."""
+    g = golden('pd')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx = ny = P // 2
+    bases = [str(s) for s in g['bases']]
+    nbasis = len(bases)
+    data = g['data']
+    lam, L = float(g['lam']), float(g['hessnorm'])
+    # oracle
+    opsi = owv.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, (nb, nx, ny), np.float64)
+
+    def ograd(x):
+        return ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x) - data
+    rms = np.full((nbasis, opsi.Nymax, opsi.Nxmax), 1e-3)
+    ooutvar = np.zeros((nb, nbasis, opsi.Nymax, opsi.Nxmax))
+    orew = partial(osv.l1reweight_func, opsi.dot, ooutvar, 1.0, rms, alpha=2)
+    xo, vo = osv.primal_dual_optimised(np.zeros((nb, nx, ny)), np.zeros_like(ooutvar), lam, opsi.hdot,
+                                       opsi.dot, L, None, np.ones_like(rms), orew, ograd, nu=nbasis,
+                                       tol=5e-2, maxit=40, positivity=1, maxreweight=3)
+    # device
+    dev = torch.device('cuda')
+    psi = amd.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    conv = partial(amd.psf.psf_convolve_cube, None, None, None, torch.from_numpy(psfhat).to(dev), Q)
+    datad = torch.from_numpy(data).to(dev)
+
+    def grad(x):
+        return conv(x) - datad
+    outvar = torch.zeros((nb, nbasis, psi.Nymax, psi.Nxmax), dtype=torch.float64, device=dev)
+    rew = partial(amd.misc.l1reweight_func, psi.dot, outvar, 1.0, torch.from_numpy(rms).to(dev), alpha=2)
+    x = torch.zeros((nb, nx, ny), dtype=torch.float64, device=dev)
+    v = torch.zeros_like(outvar)
+    x2, v2 = amd.pd.primal_dual_optimised(x, v, lam, psi.hdot, psi.dot, L, None,
+                                          torch.ones_like(outvar[0]), rew, grad, nu=nbasis, tol=5e-2,
+                                          maxit=40, positivity=1, maxreweight=3, verbosity=0)
+    assert x2 is x and x2.is_cuda
+    assert maxerr(x2.cpu().numpy(), xo) < 1e-9 * np.abs(xo).max()
+    assert maxerr(v2.cpu().numpy(), vo) < 1e-9 * np.abs(vo).max()
