@@ -92,6 +92,15 @@ int pfb_psfconv_apply(pfb_conv_plan* plan, int band0, int nb,
                       const void* x, const void* beam, double wsum, double sigmainv,
                       void* out, const void* dot_with, double* dot_out, void* stream);
 
+/* Same, with the three fused fp64 sums the predictive line search of pfb_pcg_solve needs:
+ * dots_out[0] = <dot_with, out>, dots_out[1] = <dot_with2, out> (0 if dot_with2 is NULL),
+ * dots_out[2] = <out, out>  -- all over the nb bands (pcg.py:91,95 and the backtracking
+ * loop :96-101 evaluated without further passes over the vectors). */
+int pfb_psfconv_apply_dots(pfb_conv_plan* plan, int band0, int nb,
+                           const void* x, const void* beam, double wsum, double sigmainv,
+                           void* out, const void* dot_with, const void* dot_with2,
+                           double* dots_out, void* stream);
+
 /* Introspection for benchmarks / tests */
 int    pfb_psfconv_plan_info(const pfb_conv_plan* plan, int* fast_path, int* vb,
                              size_t* workspace_bytes);
@@ -130,6 +139,12 @@ int pfb_axpby(int dtype, double a, const void* x, double b, void* y, size_t n,
  * mdiv <= 0 means M = identity).  NaN/Inf propagate silently exactly as in the reference.
  * Works on bands [band0, band0+nb) as ONE system (np.vdot over the whole cube, the
  * fluxmop semantics fluxmop.py:193-199); call once per band for pcg_psf semantics.
+ *
+ * backtrack: 0 = off; 1 = the reference's loop verbatim (every rejected step re-runs the
+ * vector update); 2 = predictive: the same decisions from the quadratic
+ * rnorm(alpha) = rnorm + (2 alpha <r,Ap> + alpha^2 <Ap,Ap>)/mdiv (three scalars fused into the
+ * convolution epilogue), then ONE vector update with the accepted alpha.  1 and 2 differ only
+ * by rounding in the comparison rnorm_next > rnorm.
  *
  * allreduce: optional hook for band-sharded multi-GPU solves -- called on `stream`
  * order with a device buffer of `count` doubles that must be summed in place over

@@ -15,8 +15,9 @@
 namespace pfb {
 
 // scalar slots in the device state array
-enum { S_PAP = 0, S_RHON = 1, S_NUM = 2, S_DEN = 3, S_ANY = 4, S_RHO = 5, S_ALPHA = 6,
-       S_BETA = 7, S_NSCALAR = 16 };
+enum { S_PAP = 0, S_RAP = 1, S_APAP = 2,          // <p,Ap>, <r,Ap>, <Ap,Ap>   (conv epilogue)
+       S_RHON = 3, S_NUM = 4, S_DEN = 5,          // <r',y'>, |x'-x|^2, |x'|^2 (update kernel)
+       S_ANY = 6, S_RHO = 7, S_ALPHA = 8, S_BETA = 9, S_NBT = 10, S_NSCALAR = 16 };
 
 constexpr int RED_BLOCK = 256;
 constexpr int RED_MAX_GRID = 1024;
@@ -219,7 +220,21 @@ k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__
 }
 
 // tiny scalar kernels on the device state
-__global__ void k_set_alpha(double* S) { S[S_ALPHA] = S[S_RHO] / S[S_PAP]; }
+__global__ void k_set_alpha(double* S) { S[S_ALPHA] = S[S_RHO] / S[S_PAP]; S[S_NBT] = 0.0; }
+// Predictive backtracking.  With M(r) = r/d linear, <r',M r'> along r' = r + a Ap is the
+// quadratic  rho(a) = rho + (2 a <r,Ap> + a^2 <Ap,Ap>) / d,  so the reference's loop
+// "while rnorm_next > rnorm: alpha *= 0.75" (pcg.py:96-101) is evaluated on three scalars
+// instead of three more passes over the vectors; the accepted step is then applied ONCE and
+// rnorm_next is recomputed from the actual r' exactly as the reference does.
+__global__ void k_alpha_predict(double* S, double mdiv) {
+    const double d = mdiv > 0.0 ? mdiv : 1.0;
+    const double rho = S[S_RHO], s1 = S[S_RAP] / d, s2 = S[S_APAP] / d;
+    double alpha = rho / S[S_PAP];
+    int nbt = 0;
+    while (rho + (2.0 * alpha * s1 + alpha * alpha * s2) > rho && nbt < 200) { alpha *= 0.75; ++nbt; }
+    S[S_ALPHA] = alpha;
+    S[S_NBT] = (double)nbt;
+}
 __global__ void k_scale_alpha(double* S) { S[S_ALPHA] *= 0.75; }
 __global__ void k_set_beta(double* S) { S[S_BETA] = S[S_RHON] / S[S_RHO]; }
 __global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
@@ -368,12 +383,18 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     double rho = h[S_RHO];
     int status = -1;
     while ((eps > tol || k < minit) && k < maxit) {
-        // Ap = A(p), S_PAP = <p, Ap>                      pcg.py:89-91
-        err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
+        // Ap = A(p); S_PAP = <p,Ap> (+ <r,Ap>, <Ap,Ap> for the predictive line search)  pcg.py:89-91
+        if (backtrack == 2)
+            err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);
+        else
+            err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
         if (err != PFB_OK) return err;
         res->matvecs++;
-        if ((err = reduce_hook(S_PAP, 1)) != PFB_OK) return err;
-        hipLaunchKernelGGL(k_set_alpha, dim3(1), dim3(1), 0, st, S);
+        if ((err = reduce_hook(S_PAP, backtrack == 2 ? 3 : 1)) != PFB_OK) return err;
+        if (backtrack == 2)
+            hipLaunchKernelGGL(k_alpha_predict, dim3(1), dim3(1), 0, st, S, mdiv_d);
+        else
+            hipLaunchKernelGGL(k_set_alpha, dim3(1), dim3(1), 0, st, S);
         for (;;) {
             PFB_LAUNCH_VEC(T, k_pcg_update, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
                            (const T*)rcur, (const T*)p, (const T*)Ap, xnew, rnew,
@@ -381,6 +402,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
             hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
             if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
             if ((err = fetch()) != PFB_OK) return err;
+            if (backtrack == 2) { res->backtracks += (int)h[S_NBT]; break; }
             if (backtrack && h[S_RHON] > rho) {          // pcg.py:96-101
                 hipLaunchKernelGGL(k_scale_alpha, dim3(1), dim3(1), 0, st, S);
                 res->backtracks++;

@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...) {
 // fast-path hooks (fftconv_pow2.hip)
 bool pow2_supported(const pfb_conv_plan* p);
 int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
-               double scale, double sigmainv, void* out, const void* dot_with,
+               double scale, double sigmainv, void* out, const void* dot_with, const void* dot_with2,
                hipStream_t st);
 int pow2_prepare(pfb_conv_plan* p);
 void pow2_release(pfb_conv_plan* p);
@@ -124,14 +124,14 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_row_inv_generic(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                   const T* __restrict__ x, const T* __restrict__ beam,
-                  const T* __restrict__ dot_with, T* __restrict__ out,
-                  double* __restrict__ partials, ConvDims d, FftFactors f, int band0,
-                  T scale, T sigmainv) {
+                  const T* __restrict__ dot_with, const T* __restrict__ dot_with2,
+                  T* __restrict__ out, double* __restrict__ partials, ConvDims d, FftFactors f,
+                  int band0, T scale, T sigmainv) {
     // all LDS in the one dynamic array (a static __shared__ beside it would eat into
     // the 160 KB limit and shift the 16-byte alignment of the dynamic base)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem);              // 64 B
-    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem + 64);
+    double* red = reinterpret_cast<double*>(smem);              // 3 sums x 4 waves = 96 B
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem + 128);
     cplx<T>* bufB = bufA + d.M;
     const int i = blockIdx.x;
     const int bl = blockIdx.y;
@@ -148,30 +148,39 @@ k_row_inv_generic(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ tw
     }
     cplx<T>* z = fft_lds_generic<T, true>(bufA, bufB, f, twQ, 2);
     const size_t rowoff = ((size_t)bl * d.nx + i) * d.ny;
-    double acc[1] = {0.0};
+    // fused sums: <dot_with, out>, <dot_with2, out>, <out, out>
+    double acc[3] = {0.0, 0.0, 0.0};
     for (int j = threadIdx.x; j < d.ny; j += blockDim.x) {
         const cplx<T> zz = z[j >> 1];
         T val = ((j & 1) ? zz.y : zz.x) * scale;
         if (beam) val *= beam[rowoff + j];
         val += sigmainv * x[rowoff + j];
         out[rowoff + j] = val;
-        if (dot_with) acc[0] += (double)dot_with[rowoff + j] * (double)val;
+        if (dot_with) {
+            acc[0] += (double)dot_with[rowoff + j] * (double)val;
+            if (dot_with2) acc[1] += (double)dot_with2[rowoff + j] * (double)val;
+            acc[2] += (double)val * (double)val;
+        }
     }
     if (dot_with) {
-        block_sum<1>(acc, red);
-        if (threadIdx.x == 0) partials[(size_t)bl * d.nx + i] = acc[0];
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * d.nx + i;
+            partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2];
+        }
     }
 }
 
-// sum `n` partials in a fixed order into out[0]
+// out[q] = sum of the n partials of quantity q (q < nq), fixed order => deterministic
 __global__ void __launch_bounds__(256)
-k_sum_partials(const double* __restrict__ partials, int n, double* __restrict__ out) {
+k_sum_partials(const double* __restrict__ partials, int n, int nq, double* __restrict__ out) {
     __shared__ double red[4];
-    double acc[1] = {0.0};
-    // fixed assignment of elements to threads and fixed tree => deterministic
-    for (int k = threadIdx.x; k < n; k += blockDim.x) acc[0] += partials[k];
-    block_sum<1>(acc, red);
-    if (threadIdx.x == 0) out[0] = acc[0];
+    for (int q = 0; q < nq; ++q) {
+        double acc[1] = {0.0};
+        for (int k = threadIdx.x; k < n; k += blockDim.x) acc[0] += partials[(size_t)q * n + k];
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) out[q] = acc[0];
+    }
 }
 
 static ConvDims dims_of(const pfb_conv_plan* p) {
@@ -200,9 +209,9 @@ static int upload_twiddles(int n, void** dev) {
 template <typename T>
 static int apply_generic(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
                          double scale, double sigmainv, void* out, const void* dot_with,
-                         hipStream_t st) {
+                         const void* dot_with2, hipStream_t st) {
     const ConvDims d = dims_of(p);
-    const size_t lds_row = 64 + 2 * sizeof(cplx<T>) * (size_t)p->M;
+    const size_t lds_row = 128 + 2 * sizeof(cplx<T>) * (size_t)p->M;
     const size_t lds_col = 2 * sizeof(cplx<T>) * (size_t)p->P;
     prof_mark(p, st, 0);
     hipLaunchKernelGGL((k_row_fwd_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
@@ -215,8 +224,8 @@ static int apply_generic(pfb_conv_plan* p, int band0, int nb, const void* x, con
     prof_mark(p, st, 2);
     hipLaunchKernelGGL((k_row_inv_generic<T>), dim3(p->nx, nb), dim3(256), lds_row, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const T*)x,
-                       (const T*)beam, (const T*)dot_with, (T*)out, p->partials, d, p->frow,
-                       band0, (T)scale, (T)sigmainv);
+                       (const T*)beam, (const T*)dot_with, (const T*)dot_with2, (T*)out, p->partials, d,
+                       p->frow, band0, (T)scale, (T)sigmainv);
     prof_mark(p, st, 3);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
@@ -282,7 +291,7 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
         return PFB_ERR_UNSUPPORTED;
     }
     if (!p->fast) {
-        const size_t lds_need = 64 + 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
+        const size_t lds_need = 128 + 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
         if (lds_need > 160 * 1024) {
             free(p);
             set_error("plan_create: generic path needs %zu B of LDS (> 160 KB) for grid (%d,%d); "
@@ -297,7 +306,7 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
     const size_t pbytes = csz * p->psf_elems_per_band * nband;
     if (rc == PFB_OK && hipMalloc(&p->T, tbytes) != hipSuccess) rc = PFB_ERR_ALLOC;
     if (rc == PFB_OK && hipMalloc(&p->psf_l, pbytes) != hipSuccess) rc = PFB_ERR_ALLOC;
-    if (rc == PFB_OK && hipMalloc((void**)&p->partials, sizeof(double) * (size_t)nx * nband) != hipSuccess)
+    if (rc == PFB_OK && hipMalloc((void**)&p->partials, sizeof(double) * 3 * (size_t)nx * nband) != hipSuccess)
         rc = PFB_ERR_ALLOC;
     if (rc == PFB_OK) {
         p->workspace_bytes = tbytes + pbytes;
@@ -385,31 +394,46 @@ int pfb_psfconv_set_psfhat(pfb_conv_plan* p, const void* psfhat, void* stream) {
     return PFB_OK;
 }
 
-int pfb_psfconv_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
-                      double wsum, double sigmainv, void* out, const void* dot_with,
-                      double* dot_out, void* stream) {
+static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                        double wsum, double sigmainv, void* out, const void* dot_with,
+                        const void* dot_with2, double* dots_out, int ndots, void* stream) {
     PFB_REQUIRE(p && x && out, PFB_ERR_INVALID, "apply: null argument");
     PFB_REQUIRE(p->have_psf, PFB_ERR_INVALID, "apply: pfb_psfconv_set_psfhat was never called");
     PFB_REQUIRE(band0 >= 0 && nb > 0 && band0 + nb <= p->nband, PFB_ERR_INVALID,
                 "apply: band range [%d,%d) outside plan (nband=%d)", band0, band0 + nb, p->nband);
     PFB_REQUIRE(x != out, PFB_ERR_INVALID, "apply: out must not alias x");
-    PFB_REQUIRE(!dot_with || dot_out, PFB_ERR_INVALID, "apply: dot_with given without dot_out");
+    PFB_REQUIRE(!dot_with || dots_out, PFB_ERR_INVALID, "apply: dot_with given without an output");
+    PFB_REQUIRE(!dot_with2 || dot_with, PFB_ERR_INVALID, "apply: dot_with2 needs dot_with");
     hipStream_t st = as_stream(stream);
     double scale = 1.0 / ((double)p->P * (double)p->Q);
     if (wsum > 0) scale /= wsum;
     int rc;
     if (p->fast)
-        rc = pow2_apply(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+        rc = pow2_apply(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     else if (p->dtype == PFB_F32)
-        rc = apply_generic<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+        rc = apply_generic<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     else
-        rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+        rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     if (rc != PFB_OK) return rc;
     if (dot_with) {
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials, p->partials_per_band * nb, dot_out);
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials,
+                           p->partials_per_band * nb, ndots, dots_out);
         PFB_HIP_CHECK(hipGetLastError());
     }
     return PFB_OK;
+}
+
+int pfb_psfconv_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                      double wsum, double sigmainv, void* out, const void* dot_with,
+                      double* dot_out, void* stream) {
+    return apply_common(p, band0, nb, x, beam, wsum, sigmainv, out, dot_with, nullptr, dot_out, 1, stream);
+}
+
+int pfb_psfconv_apply_dots(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                           double wsum, double sigmainv, void* out, const void* dot_with,
+                           const void* dot_with2, double* dots_out, void* stream) {
+    PFB_REQUIRE(dot_with && dots_out, PFB_ERR_INVALID, "apply_dots: dot_with and dots_out are required");
+    return apply_common(p, band0, nb, x, beam, wsum, sigmainv, out, dot_with, dot_with2, dots_out, 3, stream);
 }
 
 }  // extern "C"

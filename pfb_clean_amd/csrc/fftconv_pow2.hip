@@ -53,7 +53,7 @@ constexpr int row_groups() {
     constexpr int TPB = L / E;
     int G = 256 / TPB > 8 ? 256 / TPB : 8;
     const int stride = (L + L / 16 + 4);
-    while (G > 2 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 64 > LDS_BUDGET)) G /= 2;
+    while (G > 2 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 384 > LDS_BUDGET)) G /= 2;
     return G;
 }
 template <int H, int E>
@@ -472,7 +472,7 @@ __global__ void __launch_bounds__((row_groups<T, L, E>() * (L / E)))
 k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                const cplx<T>* __restrict__ twM, const cplx<T>* __restrict__ ptw,
                const T* __restrict__ x, const T* __restrict__ beam,
-               const T* __restrict__ dot_with, T* __restrict__ out,
+               const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
                double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv) {
     using F = RegFft<T, L, E>;
     constexpr int TPB = F::TPB;
@@ -482,8 +482,8 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     constexpr int HP = G / 2;
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* red = reinterpret_cast<double*>(smem);                 // 16 waves * 8 B = 128 B
-    cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem + 128);
+    double* red = reinterpret_cast<double*>(smem);                 // 3 sums * 16 waves * 8 B
+    cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem + 384);
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* lds = lds0 + (size_t)g * STRIDE;
     const int i0 = blockIdx.x * G;
@@ -497,8 +497,9 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     const V2* xr = reinterpret_cast<const V2*>(x + rowoff);
     const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) : nullptr;
     const V2* dr = dot_with ? reinterpret_cast<const V2*>(dot_with + rowoff) : nullptr;
+    const V2* dr2 = dot_with2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) : nullptr;
     V2* orow = reinterpret_cast<V2*>(out + rowoff);
-    double acc[1] = {0.0};
+    double acc[3] = {0.0, 0.0, 0.0};       // <dot_with,out>, <dot_with2,out>, <out,out>
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int n = t + TPB * j;
@@ -514,6 +515,11 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
         if (dr) {
             const V2 dw = dr[n];
             acc[0] += (double)dw.x * (double)val.x + (double)dw.y * (double)val.y;
+            if (dr2) {
+                const V2 d2 = dr2[n];
+                acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
+            }
+            acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
         }
         // keep at most 4 elements' worth of x/beam/dot_with/twiddle loads in flight: the
         // scheduler otherwise hoists all 4*E loads to the top and spills
@@ -521,8 +527,11 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     }
     if (dot_with) {
         __syncthreads();
-        block_sum<1>(acc, red);
-        if (threadIdx.x == 0) partials[(size_t)bl * gridDim.x + blockIdx.x] = acc[0];
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * gridDim.x + blockIdx.x;
+            partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2];
+        }
     }
 }
 
@@ -701,21 +710,21 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, in
 template <typename T, int L>
 static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, const void* x,
                            const void* beam, double scale, double sigmainv, void* out,
-                           const void* dot_with, hipStream_t st) {
+                           const void* dot_with, const void* dot_with2, hipStream_t st) {
     constexpr int E = FastCfg<T>::EROW;
     using F = RegFft<T, L, E>;
     constexpr int G = row_groups<T, L, E>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
-    const size_t lds = 128 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
+    const size_t lds = 384 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,
                        (const cplx<T>*)ft->ptw_row, (const T*)x, (const T*)beam, (const T*)dot_with,
-                       (T*)out, p->partials, d, band0, (T)scale, (T)sigmainv);
+                       (const T*)dot_with2, (T*)out, p->partials, d, band0, (T)scale, (T)sigmainv);
 }
 
 template <typename T>
 static int apply_t(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam, double scale,
-                   double sigmainv, void* out, const void* dot_with, hipStream_t st) {
+                   double sigmainv, void* out, const void* dot_with, const void* dot_with2, hipStream_t st) {
     const FastTables* ft = (const FastTables*)p->fast_tables;
     const int H = p->nx, L = p->ny / 2;
     prof_mark(p, st, 0);
@@ -734,7 +743,7 @@ static int apply_t(pfb_conv_plan* p, int band0, int nb, const void* x, const voi
     }
     prof_mark(p, st, 2);
     switch (L) {
-#define X(NN) case NN: launch_row_inv<T, NN>(p, ft, band0, nb, x, beam, scale, sigmainv, out, dot_with, st); break;
+#define X(NN) case NN: launch_row_inv<T, NN>(p, ft, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st); break;
         PFB_POW2_SIZES(X)
 #undef X
         default: break;
@@ -745,9 +754,9 @@ static int apply_t(pfb_conv_plan* p, int band0, int nb, const void* x, const voi
 }
 
 int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam, double scale,
-               double sigmainv, void* out, const void* dot_with, hipStream_t st) {
-    return p->dtype == PFB_F32 ? apply_t<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st)
-                               : apply_t<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, st);
+               double sigmainv, void* out, const void* dot_with, const void* dot_with2, hipStream_t st) {
+    return p->dtype == PFB_F32 ? apply_t<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st)
+                               : apply_t<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
 }
 
 }  // namespace pfb

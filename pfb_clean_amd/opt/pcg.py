@@ -22,6 +22,7 @@ break-before-increment on an all-zero direction, "Initial residual is zero" retu
 import ctypes as C
 import functools
 import math
+import os
 import sys
 
 import numpy as np
@@ -67,6 +68,17 @@ def _as_hessian(A, b):
         return HessianPsf(psfhat, nx, ny, lastsize, beam=beam,
                           sigmainv=kw.get('sigmainv', 1), wsum=kw.get('wsum', None))
     return None
+
+
+def _backtrack_mode(backtrack):
+    """False -> 0; True -> 2 (predictive line search, same decisions as pcg.py:96-101 from
+    three fused scalars) unless PFB_PCG_EXACT_BACKTRACK=1 or backtrack == 'exact' -> 1 (the
+    reference loop verbatim, one extra vector pass per rejected step)."""
+    if not backtrack:
+        return 0
+    if backtrack == 'exact' or os.environ.get('PFB_PCG_EXACT_BACKTRACK', '0') == '1':
+        return 1
+    return 2
 
 
 class _Work:
@@ -121,7 +133,7 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
     _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
                                  _dev.ptr(A.beam), A.wsum if A.wsum is not None else 0.0,
                                  A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
-                                 int(bool(backtrack)), _dev.ptr(work), cb, None, C.byref(res),
+                                 _backtrack_mode(backtrack), _dev.ptr(work), cb, None, C.byref(res),
                                  _dev.stream()))
     if squeeze:
         x = x[0]

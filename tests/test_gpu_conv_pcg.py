@@ -274,15 +274,17 @@ def test_pcg_backtracking_golden(amd, golden):
     sigmainv, Q = float(g['sigmainv']), int(g['Q'])
     nx, ny = bb.shape
     A = amd.hessian.HessianPsf(ph, nx, ny, Q, sigmainv=sigmainv)
-    total_bt = 0
-    for bt in (True, False):
+    # True = predictive line search (three fused scalars), 'exact' = the reference loop verbatim
+    counts = {}
+    for bt in (True, 'exact', False):
         for k in (3, 8):
             x, _, res = amd.pcg.pcg_fused(A, torch.from_numpy(bb).cuda(), None, tol=0.0, maxit=k,
                                           minit=k, backtrack=bt)
-            assert relerr(x.cpu().numpy(), g[f'indef_k{k}_bt{int(bt)}']) < 1e-8
+            assert relerr(x.cpu().numpy(), g[f'indef_k{k}_bt{int(bool(bt))}']) < 1e-8, (bt, k)
             assert res.iters == k and res.matvecs == k + 1
-            total_bt += res.backtracks
-    assert total_bt > 0
+            counts[(bt, k)] = res.backtracks
+    assert counts[(True, 8)] > 0 and counts[(True, 8)] == counts[('exact', 8)]
+    assert counts[(False, 8)] == 0
 
 
 def test_pcg_tensor_inputs_stay_on_device(amd, golden):
