@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpfb_hip.so')
+LIB_PATH = os.environ.get('PFB_HIP_LIB') or os.path.join(_HERE, 'libpfb_hip.so')   # override: A/B builds
 
 PFB_F32, PFB_F64 = 0, 1
 PFB_OK = 0

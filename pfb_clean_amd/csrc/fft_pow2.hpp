@@ -23,22 +23,27 @@ namespace pfb {
 constexpr int ilog2(int n) { return n <= 1 ? 0 : 1 + ilog2(n >> 1); }
 constexpr int imin(int a, int b) { return a < b ? a : b; }
 
+// largest radix done in registers: min(E, 16); a thread with E > 16 elements runs E/16
+// radix-16 butterflies per pass
+constexpr int rmax_of(int E) { return E < 16 ? E : 16; }
+
 // radix of the pass that starts with P elements already combined
-template <int N, int E, int P> struct PassRadix { static constexpr int R = imin(E, N / P); };
+template <int N, int E, int P> struct PassRadix { static constexpr int R = imin(rmax_of(E), N / P); };
 
 // offset (in elements) of pass-with-product-P's twiddle block inside the ptw table
 template <int N, int E, int P>
 struct PtwOffset {
     // passes before this one: products 1 (no twiddles), E, E^2, ...
-    static constexpr int prev = P / E;          // product at the previous pass (P = prev * E)
-    static constexpr int value = (P <= E) ? 0 : PtwOffset<N, E, (P / E < 1 ? 1 : P / E)>::value + 4 * prev;
+    static constexpr int RM = rmax_of(E);
+    static constexpr int prev = P / RM;         // product at the previous pass (P = prev * RM)
+    static constexpr int value = (P <= RM) ? 0 : PtwOffset<N, E, (P / RM < 1 ? 1 : P / RM)>::value + 4 * prev;
 };
 template <int N, int E> struct PtwOffset<N, E, 1> { static constexpr int value = 0; };
 
 template <int N, int E>
 constexpr int ptw_total() {
     int tot = 0;
-    for (int P = E; P < N; P *= E) tot += 4 * P;
+    for (int P = rmax_of(E); P < N; P *= rmax_of(E)) tot += 4 * P;
     return tot;
 }
 
@@ -47,8 +52,8 @@ template <typename T, int N, int E>
 void fill_ptw(cplx<T>* out) {
     const long double two_pi = 6.283185307179586476925286766559005768L;
     int off = 0;
-    for (int P = E; P < N; P *= E) {
-        const int R = imin(E, N / P);
+    for (int P = rmax_of(E); P < N; P *= rmax_of(E)) {
+        const int R = imin(rmax_of(E), N / P);
         for (int m = 0; m < 4; ++m)
             for (int k = 0; k < P; ++k) {
                 long double a = two_pi * (long double)((long long)(1 << m) * k) / (long double)((long long)P * R);
@@ -160,9 +165,17 @@ template <typename T, bool INV> struct Dft<T, INV, 16> {
 };
 
 // ------------------------------------------------------------------- the group FFT
-template <typename T, int N, int E>
+// WAVE: the TPB threads of a group sit inside ONE wavefront (TPB <= 64): the LDS exchanges
+// then need no s_barrier at all -- a wave's DS instructions execute in order, so its reads
+// see its own earlier writes; only the compiler must be kept from reordering them.
+template <typename T, int N, int E, bool WAVE = false>
 struct RegFft {
     static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
+    static_assert(!WAVE || N / E <= 64, "wave-local exchange needs the group inside one wave");
+    __device__ __forceinline__ static void sync() {
+        if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        else __syncthreads();
+    }
     static constexpr int TPB = N / E;
     static constexpr int LDS_ELEMS = N + N / 16;
     static constexpr int PTW = ptw_total<N, E>();
@@ -240,7 +253,7 @@ struct RegFft {
 #pragma unroll
         for (int n = 0; n < NV; ++n) butterflies<INV, P>(v[n], t, ptw);
         if constexpr (P * R < N) {
-            __syncthreads();                       // previous readers of `lds` are done
+            sync();                                // previous readers of `lds` are done
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int i = t + TPB * q;
@@ -252,7 +265,7 @@ struct RegFft {
                     for (int s = 0; s < R; ++s) wp[n * LDS_ELEMS + cpad(s * P)] = v[n][q + s * NB];
                 }
             }
-            __syncthreads();
+            sync();
             const cplx<T>* rp = lds + pad(t);
 #pragma unroll
             for (int n = 0; n < NV; ++n) {

@@ -42,16 +42,32 @@ namespace pfb {
 template <typename T> struct FastCfg;
 // NVB: frequency columns per block of the T / psf_l layout = columns per 16-byte access
 // (2 x complex64, 1 x complex128), so that 8 rows of a block form one 128-byte line.
-template <> struct FastCfg<float>  { static constexpr int ECOL = 8; static constexpr int EROW = 16; static constexpr int WCOL = 4; static constexpr int NVB = 2; };
-template <> struct FastCfg<double> { static constexpr int ECOL = 8; static constexpr int EROW = 8;  static constexpr int WCOL = 2; static constexpr int NVB = 1; };
+template <> struct FastCfg<float>  { static constexpr int ECOL = 8; static constexpr int EROWMAX = 32; static constexpr int WCOL = 4; static constexpr int NVB = 2; };
+template <> struct FastCfg<double> { static constexpr int ECOL = 8; static constexpr int EROWMAX = 16; static constexpr int WCOL = 2; static constexpr int NVB = 1; };
+
+// Row kernels: one WAVE per image row whenever the row transform fits 64 lanes x E registers
+// (E <= 32 fp32 / 16 fp64): the FFT exchanges are then wave-local (no s_barrier, the 8 waves
+// of a workgroup drift freely and overlap each other's memory phases) and nothing spills.
+// Measured on MI355X at 4096^2 x 8 bands (ms per launch, fwd / inv):
+//   E=16 G=8 (16 waves/CU, 128-B pieces): 0.570 / 1.420     E=16 G=4: 0.569 / 1.312
+//   E=8  G=4 (32 waves/CU,  64-B pieces): 0.622 / 1.116     E=32 G=8 (wave per row): 0.603 / 1.673
+// -> occupancy beats piece size for the latency-bound inverse kernel; the forward kernel
+// keeps 8 rows per workgroup (its strided side is the WRITE, full 128-byte lines).
+template <typename T, int L, bool INVK> struct RowCfg {
+    static constexpr int EMAX = INVK ? 8 : (sizeof(T) == 4 ? 16 : 8);
+    static constexpr int E = (L / 64 < 8) ? 8 : (L / 64 > EMAX ? EMAX : L / 64);
+    static constexpr int TPB = L / E;
+    static constexpr bool WAVE = TPB <= 64;
+    static constexpr int GMAX = INVK ? 4 : 8;
+};
 
 constexpr int LDS_BUDGET = 152 * 1024;
 
 // rows per workgroup for the row kernels
-template <typename T, int L, int E>
+template <typename T, int L, int E, int GMAX>
 constexpr int row_groups() {
     constexpr int TPB = L / E;
-    int G = 256 / TPB > 8 ? 256 / TPB : 8;
+    int G = 256 / TPB > GMAX ? 256 / TPB : GMAX;
     const int stride = (L + L / 16 + 4);
     while (G > 2 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 384 > LDS_BUDGET)) G /= 2;
     return G;
@@ -334,9 +350,9 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
                                               const cplx<T>* __restrict__ ptw, cplx<T>* lds0,
                                               cplx<T>* lds, cplx<T>* __restrict__ Tb, int nx, int i0,
                                               int t) {
-    using F = RegFft<T, L, E>;
+    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
     constexpr int TPB = F::TPB;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
     using V2 = typename vec2<T>::type;
@@ -357,8 +373,9 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
             vv[j] = PAR ? zz * tm[TPB * j] : zz;
         }
     }
+    __syncthreads();                             // the previous parity's cross-row reads are done
     F::template run<false>(vv, lds, t, ptw);
-    __syncthreads();                             // everyone finished the last exchange read
+    F::sync();                                   // own group finished the last exchange read
     {
         cplx<T>* wp = lds + F::pad(t);
 #pragma unroll
@@ -395,13 +412,13 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
 }
 
 template <typename T, int L, int E>
-__global__ void __launch_bounds__((row_groups<T, L, E>() * (L / E)))
+__global__ void __launch_bounds__((row_groups<T, L, E, RowCfg<T, L, false>::GMAX>() * (L / E)))
 k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw,
                const cplx<T>* __restrict__ twQ, const cplx<T>* __restrict__ twM,
                const cplx<T>* __restrict__ ptw, FastDims d, int band0) {
-    using F = RegFft<T, L, E>;
+    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
     constexpr int TPB = F::TPB;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
     constexpr int HP = G / 2;                    // row pairs
@@ -431,9 +448,9 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
                                               const cplx<T>* __restrict__ ptw, cplx<T>* lds0,
                                               cplx<T>* lds, int nx, int i0, int t,
                                               cplx<T> (&vv)[E]) {
-    using F = RegFft<T, L, E>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int TPB = F::TPB;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
     const int rr = threadIdx.x % G, bi = threadIdx.x / G;
@@ -463,20 +480,22 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
         ym = conj(ym);
         const cplx<T> w = twQ[2 * m + PAR];
         vv[j] = (yv + ym) + mul_i(mulc(yv - ym, w));
+        // bound the number of LDS / twiddle loads in flight (else all 3 E are hoisted: spills)
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     F::template run<true>(vv, lds, t, ptw);
 }
 
 template <typename T, int L, int E>
-__global__ void __launch_bounds__((row_groups<T, L, E>() * (L / E)))
+__global__ void __launch_bounds__((row_groups<T, L, E, RowCfg<T, L, true>::GMAX>() * (L / E)))
 k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                const cplx<T>* __restrict__ twM, const cplx<T>* __restrict__ ptw,
                const T* __restrict__ x, const T* __restrict__ beam,
                const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
                double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv) {
-    using F = RegFft<T, L, E>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int TPB = F::TPB;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
     constexpr int HP = G / 2;
@@ -538,7 +557,8 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
 // -------------------------------------------------------------------- host side
 struct FastTables {            // device tables owned by the plan (stored behind p->fast_tables)
     void* ptw_col;
-    void* ptw_row;
+    void* ptw_row;             // forward row kernel (E = 16)
+    void* ptw_row_inv;         // inverse row kernel (E = 8)
     void* twM;                 // exp(-2 pi i n / M), n < L
     int col_persistent;        // PFB_COL_PERSIST (default 0): persistent prefetching column kernel
     int num_cu;
@@ -578,10 +598,11 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     if (rc != PFB_OK) return rc;
     rc = PFB_ERR_UNSUPPORTED;
     switch (L) {
-#define X(NN) case NN: rc = prep_ptw<T, NN, FastCfg<T>::EROW>(&ft->ptw_row);                          \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2<T, NN, FastCfg<T>::EROW>, \
+#define X(NN) case NN: rc = prep_ptw<T, NN, RowCfg<T, NN, false>::E>(&ft->ptw_row);                   \
+        if (rc == PFB_OK) rc = prep_ptw<T, NN, RowCfg<T, NN, true>::E>(&ft->ptw_row_inv);            \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2<T, NN, RowCfg<T, NN, false>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, FastCfg<T>::EROW>, \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, RowCfg<T, NN, true>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -601,7 +622,7 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
 }
 
 template <typename T, int L>
-static int rows_per_wg() { return row_groups<T, L, FastCfg<T>::EROW>(); }
+static int rows_per_wg() { return row_groups<T, L, RowCfg<T, L, true>::E, RowCfg<T, L, true>::GMAX>(); }
 
 bool pow2_supported(const pfb_conv_plan* p) {
     if (!is_pow2(p->nx) || !is_pow2(p->ny)) return false;
@@ -648,6 +669,7 @@ void pow2_release(pfb_conv_plan* p) {
     if (!ft) return;
     if (ft->ptw_col) (void)hipFree(ft->ptw_col);
     if (ft->ptw_row) (void)hipFree(ft->ptw_row);
+    if (ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv);
     if (ft->twM) (void)hipFree(ft->twM);
     free(ft);
     p->fast_tables = nullptr;
@@ -697,9 +719,9 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
 template <typename T, int L>
 static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, const void* x,
                            const void* beam, hipStream_t st) {
-    constexpr int E = FastCfg<T>::EROW;
-    using F = RegFft<T, L, E>;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int E = RowCfg<T, L, false>::E;
+    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
     const size_t lds = sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
     hipLaunchKernelGGL((k_row_fwd_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
@@ -711,14 +733,14 @@ template <typename T, int L>
 static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, const void* x,
                            const void* beam, double scale, double sigmainv, void* out,
                            const void* dot_with, const void* dot_with2, hipStream_t st) {
-    constexpr int E = FastCfg<T>::EROW;
-    using F = RegFft<T, L, E>;
-    constexpr int G = row_groups<T, L, E>();
+    constexpr int E = RowCfg<T, L, true>::E;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
+    constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
     const size_t lds = 384 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,
-                       (const cplx<T>*)ft->ptw_row, (const T*)x, (const T*)beam, (const T*)dot_with,
+                       (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam, (const T*)dot_with,
                        (const T*)dot_with2, (T*)out, p->partials, d, band0, (T)scale, (T)sigmainv);
 }
 
