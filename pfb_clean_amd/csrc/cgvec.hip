@@ -16,8 +16,11 @@ namespace pfb {
 
 // scalar slots in the device state array
 enum { S_PAP = 0, S_RAP = 1, S_APAP = 2,          // <p,Ap>, <r,Ap>, <Ap,Ap>   (conv epilogue)
-       S_RHON = 3, S_NUM = 4, S_DEN = 5,          // <r',y'>, |x'-x|^2, |x'|^2 (update kernel)
-       S_ANY = 6, S_RHO = 7, S_ALPHA = 8, S_BETA = 9, S_NBT = 10, S_NSCALAR = 16 };
+       S_ANY = 3,                                 // count(p != 0) of the direction in use
+       S_RHON = 4, S_NUM = 5, S_DEN = 6,          // <r',y'>, |x'-x|^2, |x'|^2 (update kernel)
+       S_RHO = 7, S_ALPHA = 8, S_BETA = 9, S_NBT = 10,
+       S_DEAD = 11,                               // p became all-zero: later work is a no-op
+       S_K = 12, S_EPS = 13, S_EPSP = 14, S_NBTSUM = 15, S_NSCALAR = 16 };
 
 constexpr int RED_BLOCK = 256;
 constexpr int RED_MAX_GRID = 1024;
@@ -173,7 +176,10 @@ k_pcg_update(const T* __restrict__ x, const T* __restrict__ r, const T* __restri
              const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
              const double* __restrict__ alpha_dev, T mdiv, size_t nvec,
              double* __restrict__ ws) {
-    const T alpha = (T)alpha_dev[0];
+    // alpha_dev points at S[S_ALPHA]; once the solve is "dead" (all-zero direction,
+    // pcg.py:106-107 detected one iteration late) the step is forced to 0: x' = x, r' = r
+    const bool dead = alpha_dev[S_DEAD - S_ALPHA] != 0.0;
+    const T alpha = dead ? T(0) : (T)alpha_dev[0];
     double acc[3] = {0.0, 0.0, 0.0};
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -202,8 +208,12 @@ template <typename T, int V>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__ beta_dev,
           T mdiv, size_t nvec, double* __restrict__ ws) {
-    const T beta = (T)beta_dev[0];
     double acc[1] = {0.0};
+    if (beta_dev[S_DEAD - S_BETA] != 0.0) {        // dead: leave p (all zero) alone
+        emit_partials<1>(acc, ws);
+        return;
+    }
+    const T beta = (T)beta_dev[0];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
          i += (size_t)gridDim.x * blockDim.x) {
         Pack<T, V> pp = ld<T, V>(p, i), pr = ld<T, V>(r, i);
@@ -238,6 +248,44 @@ __global__ void k_alpha_predict(double* S, double mdiv) {
 __global__ void k_scale_alpha(double* S) { S[S_ALPHA] *= 0.75; }
 __global__ void k_set_beta(double* S) { S[S_BETA] = S[S_RHON] / S[S_RHO]; }
 __global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
+
+// ---- device-side loop bookkeeping of the sync-free driver
+__global__ void k_iter_begin(double* S, double mdiv, int predict) {
+    if (S[S_DEAD] != 0.0) return;
+    if (S[S_ANY] == 0.0) {                 // the direction built last iteration is all zero:
+        S[S_DEAD] = 1.0;                   // the reference broke BEFORE k += 1 (pcg.py:106-108)
+        S[S_K] -= 1.0;
+        S[S_EPS] = S[S_EPSP];
+        return;
+    }
+    const double rho = S[S_RHO];
+    double alpha = rho / S[S_PAP];
+    int nbt = 0;
+    if (predict) {
+        const double d = mdiv > 0.0 ? mdiv : 1.0;
+        const double s1 = S[S_RAP] / d, s2 = S[S_APAP] / d;
+        while (rho + (2.0 * alpha * s1 + alpha * alpha * s2) > rho && nbt < 200) { alpha *= 0.75; ++nbt; }
+    }
+    S[S_ALPHA] = alpha;
+    S[S_NBT] = (double)nbt;
+}
+__global__ void k_iter_end(double* S) {
+    if (S[S_DEAD] != 0.0) return;
+    S[S_BETA] = S[S_RHON] / S[S_RHO];
+    S[S_RHO] = S[S_RHON];
+    S[S_K] += 1.0;
+    S[S_EPSP] = S[S_EPS];
+    S[S_EPS] = sqrt(S[S_NUM] / (1e-12 + S[S_DEN]));
+    S[S_NBTSUM] += S[S_NBT];
+}
+__global__ void k_final_check(double* S) {
+    if (S[S_DEAD] == 0.0 && S[S_ANY] == 0.0) { S[S_DEAD] = 1.0; S[S_K] -= 1.0; S[S_EPS] = S[S_EPSP]; }
+}
+__global__ void k_init_state(double* S) {
+    S[S_RHO] = S[S_RHON];
+    S[S_ANY] = S[S_NUM];                   // count(y != 0) = count(p != 0) for p = -y
+    S[S_EPS] = 1.0; S[S_EPSP] = 1.0;
+}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -367,7 +415,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 2, S + S_RHON);
     // S_RHON = <r,y>, S_NUM = count(y != 0): move into place after the hook
     if ((err = reduce_hook(S_RHON, 2)) != PFB_OK) return err;
-    hipLaunchKernelGGL(k_accept_rho, dim3(1), dim3(1), 0, st, S);
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, st, S);
     if ((err = fetch()) != PFB_OK) return err;
     if (h[S_NUM] == 0.0) {                               // "Initial residual is zero"
         res->status = PFB_PCG_ZERO_RESIDUAL;
@@ -382,7 +430,53 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     double eps = 1.0;
     double rho = h[S_RHO];
     int status = -1;
-    while ((eps > tol || k < minit) && k < maxit) {
+    if (backtrack != 1) {
+        // ---- sync-free driver (backtrack off or predictive).  Everything an iteration
+        // needs to decide lives in S on the device; the host only has to look when the
+        // stopping rule `(eps > tol or k < minit) and k < maxit` can actually fire, i.e.
+        // never while k < minit.  Two all-reduce points per iteration:
+        //   [p.Ap, r.Ap, Ap.Ap, any(p)]  and  [r'.y', |x'-x|^2, |x'|^2].
+        int khost = 0;
+        bool go = (1.0 > tol || 0 < minit) && 0 < maxit;
+        while (go) {
+            if (backtrack == 2)
+                err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);
+            else
+                err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
+            if (err != PFB_OK) return err;
+            if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
+            hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 1 : 0);
+            PFB_LAUNCH_VEC(T, k_pcg_update, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
+                           (const T*)rcur, (const T*)p, (const T*)Ap, xnew, rnew,
+                           (const double*)(S + S_ALPHA), mdiv);
+            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
+            if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
+            hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S);
+            { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
+            PFB_LAUNCH_VEC(T, k_pcg_dir, n, (PL{p, rcur}), p, (const T*)rcur, (const double*)(S + S_BETA), mdiv);
+            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, S + S_ANY);
+            ++khost;
+            if (khost < minit && khost < maxit) continue;          // cannot stop yet: no need to look
+            if ((err = fetch()) != PFB_OK) return err;
+            k = (int)h[S_K];
+            eps = h[S_EPS];
+            if (h[S_DEAD] != 0.0) { status = PFB_PCG_BREAKDOWN; break; }
+            go = (eps > tol || k < minit) && k < maxit;
+        }
+        if (status < 0) {
+            // the direction built by the last iteration has not been looked at yet
+            if ((err = reduce_hook(S_ANY, 1)) != PFB_OK) return err;
+            hipLaunchKernelGGL(k_final_check, dim3(1), dim3(1), 0, st, S);
+            if ((err = fetch()) != PFB_OK) return err;
+            if (h[S_DEAD] != 0.0) status = PFB_PCG_BREAKDOWN;
+        }
+        k = (int)h[S_K];
+        eps = h[S_EPS];
+        rho = h[S_RHO];
+        res->backtracks = (int)h[S_NBTSUM];
+        res->matvecs = 1 + k + (status == PFB_PCG_BREAKDOWN ? 1 : 0);
+    }
+    while (backtrack == 1 && (eps > tol || k < minit) && k < maxit) {
         // Ap = A(p); S_PAP = <p,Ap> (+ <r,Ap>, <Ap,Ap> for the predictive line search)  pcg.py:89-91
         if (backtrack == 2)
             err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);

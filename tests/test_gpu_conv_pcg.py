@@ -287,6 +287,25 @@ def test_pcg_backtracking_golden(amd, golden):
     assert counts[(False, 8)] == 0
 
 
+@pmp('mode', [True, 'exact', False])
+def test_pcg_breakdown_all_zero_direction(amd, mode):
+    """pcg.py:106-107: `if not np.any(p): break` BEFORE k += 1.  A = identity (psfhat = 0,
+    sigmainv = 1) converges exactly in one step: r' = 0, p = 0.  The sync-free driver notices
+    one iteration late on the device and must still report k = 0 and x = b."""
+    rng = np.random.default_rng(5)
+    nx, ny = 64, 128
+    b = rng.standard_normal((1, nx, ny))
+    psfhat = np.zeros((1, 2 * nx, ny + 1), dtype=np.complex128)
+    A = amd.hessian.HessianPsf(psfhat, nx, ny, 2 * ny, sigmainv=1.0)
+    x, r, res = amd.pcg.pcg_fused(A, torch.from_numpy(b).cuda(), None, tol=1e-8, maxit=10, minit=5,
+                                  backtrack=mode, return_resid=True)
+    assert res.status == 3 and res.iters == 0 and res.matvecs == 2
+    assert np.array_equal(x.cpu().numpy(), b)
+    assert not r.cpu().numpy().any()
+    ref = osv.pcg(lambda v: v.copy(), b, None, tol=1e-8, maxit=10, minit=5, backtrack=bool(mode))
+    assert np.array_equal(ref, b)
+
+
 def test_pcg_tensor_inputs_stay_on_device(amd, golden):
     g = golden('pcg')
     psfhat, b = torch.from_numpy(g['psfhat']).cuda(), torch.from_numpy(g['b']).cuda()
