@@ -1,0 +1,122 @@
+"""
+GPU tests for (1) the RCCL all-reduce hook of the fused PCG, exercised with a real `nccl`
+process group of world size 1 (the only multi-process GPU configuration a 1-GPU box
+allows; world size 2 runs on CPU/gloo in tests/test_cpu_host.py), and (2) the BASELINE
+config #4 composition -- power_method -> pcg -> primal_dual_optimised with psi/psi^H --
+at reduced size against the CPU oracle.
+"""
+import os
+import socket
+from functools import partial
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import fftconv as ofc, solvers as osv, wavelets as owv   # noqa: E402 (checker only)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _psd_psfhat(rng, nb, P, Q):
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    W = rng.poisson(4 * np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2)), size=(nb, P, Q // 2 + 1)).astype(np.float64)
+    W /= nb * np.fft.irfft2(W, s=(P, Q)).max(axis=(1, 2))[:, None, None]
+    return W.astype(np.complex128)
+
+
+def test_pcg_allreduce_hook_with_rccl_world1():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    from pfb_clean_amd.opt.pcg import pcg_fused
+    rng = np.random.default_rng(3)
+    nb, nx, ny = 2, 128, 128
+    psfhat = _psd_psfhat(rng, nb, 2 * nx, 2 * ny)
+    b = rng.standard_normal((nb, nx, ny))
+    A = HessianPsf(torch.from_numpy(psfhat).cuda(), nx, ny, 2 * ny, sigmainv=1e-2)
+    bt = torch.from_numpy(b).cuda()
+    x_ref, _, res_ref = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(_free_port())
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        x, _, res = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True)
+        x1, _, res1 = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True,
+                                backtrack='exact')
+    finally:
+        dist.destroy_process_group()
+    assert res.iters == res_ref.iters == 8
+    assert torch.equal(x, x_ref)                   # sum over one rank: bitwise identical
+    assert (x1 - x_ref).abs().max().item() < 1e-12 * x_ref.abs().max().item()
+
+
+def test_fwdbwd_composition_config4_reduced():
+    """power_method (hessnorm) -> pcg (forward step) -> primal_dual_optimised (backward
+    step) as in workers/fwdbwd.py:310-453 with the live operators, 2 bands x 128^2,
+    bases self+db1..db3, 2 levels, everything GPU resident; oracle runs the same recipe."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.psf import psf_convolve_cube
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    from pfb_clean_amd.operators.psi import Psi
+    from pfb_clean_amd.opt.pcg import pcg, DivPrecond
+    from pfb_clean_amd.opt.power_method import power_method
+    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised
+    rng = np.random.default_rng(12)
+    nb, nx, ny = 2, 128, 128
+    P, Q = 2 * nx, 2 * ny
+    bases = ['self', 'db1', 'db2', 'db3']
+    nbasis, nlevel = len(bases), 2
+    psfhat = _psd_psfhat(rng, nb, P, Q)
+    truth = np.zeros((nb, nx, ny))
+    truth[:, 40, 50] = 1.0
+    truth[:, 80:84, 30:34] = 0.3
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, truth.shape, np.float64)
+    oconv = partial(ofc.psf_convolve_cube, xpad, xhat, xout, psfhat, Q)
+    dirty = oconv(truth).copy() + 1e-4 * rng.standard_normal(truth.shape)
+    sigmainv = 1e-3 * np.abs(dirty).max()
+    b0 = rng.standard_normal(truth.shape)
+    lam = 5e-4
+
+    # ---------------- oracle
+    L_ref, _ = osv.power_method(oconv, truth.shape, b0=b0.copy(), tol=1e-6, maxit=60)
+
+    def oA(v):
+        return ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, v, sigmainv=sigmainv)
+    xf_ref = osv.pcg(oA, dirty, None, M=lambda v: v / sigmainv, tol=0.0, maxit=15, minit=15)
+    opsi = owv.Psi(nb, nx, ny, bases, nlevel, 1)
+    data = oconv(xf_ref).copy()
+    ov = np.zeros((nb, nbasis, opsi.Nymax, opsi.Nxmax))
+    xb_ref, vb_ref = osv.primal_dual_optimised(xf_ref.copy(), ov, lam, opsi.hdot, opsi.dot, 1.05 * L_ref,
+                                               None, np.ones(ov.shape[1:]), None,
+                                               lambda v: oconv(v) - data, nu=nbasis, tol=0.0, maxit=12,
+                                               positivity=1)
+    # ---------------- device
+    dev = torch.device('cuda')
+    ph = torch.from_numpy(psfhat).to(dev)
+    conv = partial(psf_convolve_cube, None, None, None, ph, Q)
+    L, _ = power_method(conv, truth.shape, b0=torch.from_numpy(b0).to(dev), tol=1e-6, maxit=60, verbosity=0)
+    assert abs(L - L_ref) < 1e-10 * L_ref
+    A = HessianPsf(ph, nx, ny, Q, sigmainv=sigmainv)
+    xf = pcg(A, torch.from_numpy(dirty).to(dev), None, M=DivPrecond(sigmainv), tol=0.0, maxit=15, minit=15,
+             verbosity=0)
+    assert (xf.cpu().numpy() - xf_ref).__abs__().max() < 1e-9 * np.abs(xf_ref).max()
+    psi = Psi(nb, nx, ny, bases, nlevel, 1)
+    datad = conv(xf).clone()
+    v = torch.zeros((nb, nbasis, psi.Nymax, psi.Nxmax), dtype=torch.float64, device=dev)
+    xb, vb = primal_dual_optimised(xf.clone(), v, lam, psi.hdot, psi.dot, 1.05 * L, None,
+                                   torch.ones_like(v[0]), None, lambda t: conv(t) - datad, nu=nbasis,
+                                   tol=0.0, maxit=12, positivity=1, verbosity=0)
+    assert np.abs(xb.cpu().numpy() - xb_ref).max() < 1e-8 * np.abs(xb_ref).max()
+    assert np.abs(vb.cpu().numpy() - vb_ref).max() < 1e-8 * np.abs(vb_ref).max()
