@@ -155,13 +155,24 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     const cplx<T>* pe = psf_l + (size_t)band * psf_band + (b * (2 * (size_t)H) + t) * NVB;
     const cplx<T>* po = pe + (size_t)H * NVB;
 
-    cplx<T> vv[NVB][E], ev[NVB][E];
+    // a is read from HBM exactly once (rocprofv3 FETCH_SIZE showed the former "re-read from
+    // L2" going to HBM: +1 GB per 8-band launch).  aw = a .* w_P^n is formed at load time and
+    // parked in registers; its live range (first FFT pair) does not overlap ev's (second pair),
+    // so the peak register demand is unchanged.
+    cplx<T> vv[NVB][E], aw[NVB][E];
+    {
+        const cplx<T>* tw2 = twP + t;
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        Blk<T, NVB> a;
-        if (active) a = loadb<T, NVB>(col + NVB * TPB * j);
+        for (int j = 0; j < E; ++j) {
+            Blk<T, NVB> a;
+            if (active) a = loadb<T, NVB>(col + NVB * TPB * j);
+            const cplx<T> w = tw2[TPB * j];
 #pragma unroll
-        for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] : cplx<T>(0, 0);
+            for (int c = 0; c < NVB; ++c) {
+                vv[c][j] = active ? a.c[c] : cplx<T>(0, 0);
+                aw[c][j] = vv[c][j] * w;
+            }
+        }
     }
     // ---- even bins of the column transform
     F::template runN<false, NVB>(vv, lds, t, ptw);
@@ -172,24 +183,13 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
     }
     F::template runN<true, NVB>(vv, lds, t, ptw);
+    cplx<T> ev[NVB][E];
 #pragma unroll
     for (int j = 0; j < E; ++j) {
 #pragma unroll
-        for (int c = 0; c < NVB; ++c) ev[c][j] = vv[c][j];
+        for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; vv[c][j] = aw[c][j]; }
     }
-    // ---- odd bins: a .* w_P^n  (a and w re-read: L2 hits, saves live VGPRs)
-    {
-        const cplx<T>* col2 = opaque(col);
-        const cplx<T>* tw2 = opaque(twP + t);
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            Blk<T, NVB> a;
-            if (active) a = loadb<T, NVB>(col2 + NVB * TPB * j);
-            const cplx<T> w = tw2[TPB * j];
-#pragma unroll
-            for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] * w : cplx<T>(0, 0);
-        }
-    }
+    // ---- odd bins
     F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
