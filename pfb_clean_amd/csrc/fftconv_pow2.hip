@@ -392,7 +392,7 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
     constexpr int NBP = PAR ? L / NVB : NBE;                 // blocks of this parity
     constexpr int BSTEP = NT / G;
     cplx<T>* Tp = Tb + ((size_t)(PAR ? NBE : 0) * nx + i0 + rr) * NVB;
-    for (int b = bi; b < NBP; b += BSTEP) {
+    for (int b = bi; b < NBP; b += BSTEP) {       // (unrolling this loop spills: 0.52 -> 0.84 ms)
         Blk<T, NVB> o;
 #pragma unroll
         for (int h = 0; h < NVB; ++h) {
@@ -461,11 +461,23 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
     constexpr int NBP = PAR ? L / NVB : NBE;
     constexpr int BSTEP = NT / G;
     const cplx<T>* Tp = Tb + ((size_t)(PAR ? NBE : 0) * nx + i0 + rr) * NVB;
-    for (int b = bi; b < NBP; b += BSTEP) {
-        const Blk<T, NVB> y = loadb<T, NVB>(Tp + (size_t)b * nx * NVB);   // bins of block b, row rr
+    // issue ALL strided loads of this thread before the first LDS write: a rolled loop
+    // (load, wait, store, next) pays the HBM latency once per trip
+    constexpr int NIT = (NBP + BSTEP - 1) / BSTEP;
+    Blk<T, NVB> y[NIT];
 #pragma unroll
-        for (int h = 0; h < NVB; ++h)
-            if (PAR || NVB * b + h <= L) yr[F::pad(NVB * b + h)] = y.c[h];
+    for (int k = 0; k < NIT; ++k) {
+        const int b = bi + k * BSTEP;
+        if (b < NBP) y[k] = loadb<T, NVB>(Tp + (size_t)b * nx * NVB);    // bins of block b, row rr
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int b = bi + k * BSTEP;
+        if (b < NBP) {
+#pragma unroll
+            for (int h = 0; h < NVB; ++h)
+                if (PAR || NVB * b + h <= L) yr[F::pad(NVB * b + h)] = y[k].c[h];
+        }
     }
     __syncthreads();
     // Z[v] = (Y[v] + conj Y[M-v]) + i conj(w_Q^v) (Y[v] - conj Y[M-v]),  v = 2m + PAR
@@ -505,7 +517,17 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem + 384);
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* lds = lds0 + (size_t)g * STRIDE;
-    const int i0 = blockIdx.x * G;
+    // XCD-aware row-group order: with G = 4 a 128-byte line of T is shared by two row groups;
+    // workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2 --
+    // give THEM the two halves of a line (speed only, any mapping is correct).
+    int rg = blockIdx.x;
+    if constexpr (G * (int)sizeof(cplx<T>) * FastCfg<T>::NVB < 128) {
+        if ((gridDim.x & 15) == 0) {
+            const int q = blockIdx.x >> 4, rem = blockIdx.x & 15;
+            rg = 2 * (q * 8 + (rem & 7)) + (rem >> 3);
+        }
+    }
+    const int i0 = rg * G;
     const int bl = blockIdx.y, band = band0 + bl;
     const cplx<T>* Tb = Tw + (size_t)band * d.T_band;
     cplx<T> vv[E], ev[E];
@@ -548,7 +570,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
         __syncthreads();
         block_sum<3>(acc, red);
         if (threadIdx.x == 0) {
-            const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * gridDim.x + blockIdx.x;
+            const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * gridDim.x + rg;
             partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2];
         }
     }
