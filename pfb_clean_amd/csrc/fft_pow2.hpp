@@ -168,7 +168,10 @@ template <typename T, bool INV> struct Dft<T, INV, 16> {
 // WAVE: the TPB threads of a group sit inside ONE wavefront (TPB <= 64): the LDS exchanges
 // then need no s_barrier at all -- a wave's DS instructions execute in order, so its reads
 // see its own earlier writes; only the compiler must be kept from reordering them.
-template <typename T, int N, int E, bool WAVE = false>
+// DBOFF > 0: a second LDS buffer sits DBOFF elements after the first and the exchanges
+// alternate between them (first exchange -> alternate buffer), which removes the barrier
+// in front of every write: the buffer being written was last read two barriers ago.
+template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0>
 struct RegFft {
     static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
     static_assert(!WAVE || N / E <= 64, "wave-local exchange needs the group inside one wave");
@@ -245,15 +248,16 @@ struct RegFft {
     // NV independent transforms advance together: same barriers, NV LDS buffers
     // (lds + n * LDS_ELEMS), NV * E values in registers.  NV = 1 for the row kernels,
     // NV = 2 for the column kernel (two frequency columns per 16-byte access).
-    template <bool INV, int P, int NV>
-    __device__ __forceinline__ static void pass(cplx<T> (&v)[NV][E], cplx<T>* lds, int t,
+    template <bool INV, int P, int NV, int XCH = 0>
+    __device__ __forceinline__ static void pass(cplx<T> (&v)[NV][E], cplx<T>* lds_in, int t,
                                                 const cplx<T>* __restrict__ ptw) {
         constexpr int R = PassRadix<N, E, P>::R;
         constexpr int NB = E / R;
 #pragma unroll
         for (int n = 0; n < NV; ++n) butterflies<INV, P>(v[n], t, ptw);
         if constexpr (P * R < N) {
-            sync();                                // previous readers of `lds` are done
+            cplx<T>* lds = (DBOFF > 0 && (XCH & 1) == 0) ? lds_in + DBOFF : lds_in;
+            if constexpr (DBOFF == 0) sync();      // previous readers of `lds` are done
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int i = t + TPB * q;
@@ -272,7 +276,7 @@ struct RegFft {
 #pragma unroll
                 for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cpad(TPB * j)];
             }
-            pass<INV, P * R, NV>(v, lds, t, ptw);
+            pass<INV, P * R, NV, XCH + 1>(v, lds_in, t, ptw);
         }
     }
 

@@ -53,12 +53,22 @@ template <> struct FastCfg<double> { static constexpr int ECOL = 8; static const
 //   E=8  G=4 (32 waves/CU,  64-B pieces): 0.622 / 1.116     E=32 G=8 (wave per row): 0.603 / 1.673
 // -> occupancy beats piece size for the latency-bound inverse kernel; the forward kernel
 // keeps 8 rows per workgroup (its strided side is the WRITE, full 128-byte lines).
+template <typename T, int L, int E, int GMAX> constexpr int row_groups();
 template <typename T, int L, bool INVK> struct RowCfg {
     static constexpr int EMAX = INVK ? 8 : (sizeof(T) == 4 ? 16 : 8);
     static constexpr int E = (L / 64 < 8) ? 8 : (L / 64 > EMAX ? EMAX : L / 64);
     static constexpr int TPB = L / E;
     static constexpr bool WAVE = TPB <= 64;
     static constexpr int GMAX = INVK ? 4 : 8;
+};
+// inverse row kernel: second exchange buffer (one barrier per exchange instead of two)
+// whenever 2 x G rows fit the LDS
+template <typename T, int L> struct InvDb {
+    using C = RowCfg<T, L, true>;
+    static constexpr int G = row_groups<T, L, C::E, C::GMAX>();
+    static constexpr int STRIDE = L + L / 16 + 4;
+    static constexpr bool ON = (size_t)2 * G * STRIDE * sizeof(cplx<T>) + 384 <= (size_t)152 * 1024;
+    static constexpr int OFF = ON ? G * STRIDE : 0;
 };
 
 constexpr int LDS_BUDGET = 152 * 1024;
@@ -448,7 +458,7 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
                                               const cplx<T>* __restrict__ ptw, cplx<T>* lds0,
                                               cplx<T>* lds, int nx, int i0, int t,
                                               cplx<T> (&vv)[E]) {
-    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
@@ -505,7 +515,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                const T* __restrict__ x, const T* __restrict__ beam,
                const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
                double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv) {
-    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
@@ -759,7 +769,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
-    const size_t lds = 384 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
+    const size_t lds = 384 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4) * (InvDb<T, L>::ON ? 2 : 1);
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,
                        (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam, (const T*)dot_with,
