@@ -63,6 +63,21 @@ void fill_ptw(cplx<T>* out) {
     }
 }
 
+// compact table: w only (the m = 0 rows of fill_ptw), offsets off_s / 4
+template <typename T, int N, int E>
+void fill_ptw_compact(cplx<T>* out) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    int off = 0;
+    for (int P = rmax_of(E); P < N; P *= rmax_of(E)) {
+        const int R = imin(rmax_of(E), N / P);
+        for (int k = 0; k < P; ++k) {
+            long double a = two_pi * (long double)k / (long double)((long long)P * R);
+            out[off + k] = cplx<T>((T)cosl(a), (T)(-sinl(a)));
+        }
+        off += P;
+    }
+}
+
 // ------------------------------------------------------------- small in-register DFTs
 template <typename T, bool INV>
 __device__ __forceinline__ cplx<T> rot90(cplx<T> a) {   // multiply by -i (fwd) / +i (inv)
@@ -171,7 +186,12 @@ template <typename T, bool INV> struct Dft<T, INV, 16> {
 // DBOFF > 0: a second LDS buffer sits DBOFF elements after the first and the exchanges
 // alternate between them (first exchange -> alternate buffer), which removes the barrier
 // in front of every write: the buffer being written was last read two barriers ago.
-template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0>
+// SQTW: `ptw` is the COMPACT table (w only: ptw_c[off_s/4 + k]) and w^2, w^4, w^8 are
+// formed by squaring.  The compact table is small enough (sum of P_s elements) to be copied
+// into LDS by the kernel, which takes every global load out of the passes: s_waitcnt vmcnt
+// is in-order, so a twiddle load inside a pass would force every older, deliberately
+// early-issued load (prefetch of the next operand) to complete first.
+template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0, bool SQTW = false>
 struct RegFft {
     static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
     static_assert(!WAVE || N / E <= 64, "wave-local exchange needs the group inside one wave");
@@ -182,6 +202,7 @@ struct RegFft {
     static constexpr int TPB = N / E;
     static constexpr int LDS_ELEMS = N + N / 16;
     static constexpr int PTW = ptw_total<N, E>();
+    static constexpr int PTWC = ptw_total<N, E>() / 4;          // compact (w only) table size
 
     __device__ __forceinline__ static int pad(int i) { return i + (i >> 4); }
     // pad(b + c) == pad(b) + cpad(c) whenever (b & 15) + (c & 15) < 16, which holds for
@@ -201,13 +222,19 @@ struct RegFft {
             for (int r = 0; r < R; ++r) u[r] = v[q + r * NB];
             if constexpr (P > 1) {
                 const int k = (t + TPB * q) & (P - 1);
-                const cplx<T>* tb = ptw + PtwOffset<N, E, P>::value + k;
-                // w, w^2, w^4, w^8 are loaded; the other powers are formed right where
-                // they are consumed so that only a handful of twiddles is live at a time
+                const cplx<T>* tb = ptw + (SQTW ? PtwOffset<N, E, P>::value / 4 : PtwOffset<N, E, P>::value) + k;
+                // w, w^2, w^4, w^8 are loaded (or squared up from w); the other powers are
+                // formed right where they are consumed so that few twiddles are live at a time
                 cplx<T> w1 = tb[0], w2, w4, w8;
-                if constexpr (R > 2) w2 = tb[P];
-                if constexpr (R > 4) w4 = tb[2 * P];
-                if constexpr (R > 8) w8 = tb[3 * P];
+                if constexpr (SQTW) {
+                    if constexpr (R > 2) w2 = w1 * w1;
+                    if constexpr (R > 4) w4 = w2 * w2;
+                    if constexpr (R > 8) w8 = w4 * w4;
+                } else {
+                    if constexpr (R > 2) w2 = tb[P];
+                    if constexpr (R > 4) w4 = tb[2 * P];
+                    if constexpr (R > 8) w8 = tb[3 * P];
+                }
                 if constexpr (INV) {
                     w1.y = -w1.y;
                     if constexpr (R > 2) w2.y = -w2.y;

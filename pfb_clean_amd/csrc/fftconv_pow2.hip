@@ -233,21 +233,23 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 template <typename T, int H, int E>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), 2)
 k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
-            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
+            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
             int nblk, int nitems, size_t T_band, size_t psf_band, int band0) {
-    using F = RegFft<T, H, E>;
+    using F = RegFft<T, H, E, false, 0, true>;           // twiddles from LDS: no vmcnt wait in the passes
     constexpr int TPB = F::TPB;
     constexpr int NVB = FastCfg<T>::NVB;
     constexpr int GC = col_groups<H, E>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
-    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem) + (size_t)g * (NVB * F::LDS_ELEMS);
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* lds = ltw + ((F::PTWC + 1) & ~1) + (size_t)g * (NVB * F::LDS_ELEMS);
     const int stride = gridDim.x * GC;
     const int niter = (nitems + stride - 1) / stride;           // same for every workgroup
 
     cplx<T> tw[E];
 #pragma unroll
     for (int j = 0; j < E; ++j) tw[j] = twP[t + TPB * j];
+    for (int k = threadIdx.x; k < F::PTWC; k += GC * TPB) ltw[k] = ptwc[k];
 
     auto col_of = [&](int item) -> cplx<T>* {
         const int bl = item / nblk, blk = item - bl * nblk;
@@ -272,22 +274,23 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
     }
+    __syncthreads();                                            // twiddle table visible
 #pragma unroll 1
     for (int it = 0; it < niter; ++it, item += stride) {
         const bool active = item < nitems;
         cplx<T>* col = col_of(active ? item : 0);
         const cplx<T>* pe = psf_of(active ? item : 0);
         const cplx<T>* po = pe + (size_t)H * NVB;
-        cplx<T> vv[NVB][E], ev[NVB][E];
-        Blk<T, NVB> qe[E], qo[E];
+        cplx<T> vv[NVB][E], aw[NVB][E];
+        Blk<T, NVB> q[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
-            for (int c = 0; c < NVB; ++c) vv[c][j] = an[j].c[c];
+            for (int c = 0; c < NVB; ++c) { vv[c][j] = an[j].c[c]; aw[c][j] = vv[c][j] * tw[j]; }
         }
-        // issue everything this item still needs from HBM, then the next item's a
+        // in issue order (vmcnt retires in order): psf_e of this item, then a of the next
 #pragma unroll
-        for (int j = 0; j < E; ++j) qe[j] = loadb<T, NVB>(pe + NVB * TPB * j);
+        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
         {
             const int nxt = item + stride;
             const bool nact = nxt < nitems;
@@ -301,43 +304,30 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 }
             }
         }
-        // a copy of a for the odd-bin pass, pre-multiplied by w_P^n, parked in ev... no:
-        // ev is needed for the even result; the odd input is re-read below (L2 hit).
         // ---- even bins
-        F::template runN<false, NVB>(vv, lds, t, ptw);
+        F::template runN<false, NVB>(vv, lds, t, ltw);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
-            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * qe[j].c[c];
+            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
-        // psf_o has the inverse FFT of the even bins and the forward FFT of the odd bins
-        // (~2/3 of the item) to arrive
 #pragma unroll
-        for (int j = 0; j < E; ++j) qo[j] = loadb<T, NVB>(opaque(po) + NVB * TPB * j);
-        F::template runN<true, NVB>(vv, lds, t, ptw);
+        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+        F::template runN<true, NVB>(vv, lds, t, ltw);
+        cplx<T> ev[NVB][E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
-            for (int c = 0; c < NVB; ++c) ev[c][j] = vv[c][j];
+            for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; vv[c][j] = aw[c][j]; }
         }
-        // ---- odd bins: a .* w_P^n (a re-read from L2)
-        {
-            const cplx<T>* col2 = opaque(col);
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                Blk<T, NVB> a;
-                if (active) a = loadb<T, NVB>(col2 + NVB * TPB * j);
-#pragma unroll
-                for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a.c[c] * tw[j] : cplx<T>(0, 0);
-            }
-        }
-        F::template runN<false, NVB>(vv, lds, t, ptw);
+        // ---- odd bins
+        F::template runN<false, NVB>(vv, lds, t, ltw);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
-            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * qo[j].c[c];
+            for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
-        F::template runN<true, NVB>(vv, lds, t, ptw);
+        F::template runN<true, NVB>(vv, lds, t, ltw);
         if (active) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -589,10 +579,11 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
 // -------------------------------------------------------------------- host side
 struct FastTables {            // device tables owned by the plan (stored behind p->fast_tables)
     void* ptw_col;
+    void* ptwc_col;            // compact (w only) table of the column transform, copied to LDS
     void* ptw_row;             // forward row kernel (E = 16)
     void* ptw_row_inv;         // inverse row kernel (E = 8)
     void* twM;                 // exp(-2 pi i n / M), n < L
-    int col_persistent;        // PFB_COL_PERSIST (default 0): persistent prefetching column kernel
+    int col_persistent;        // PFB_COL_PERSIST (default: auto by size): persistent prefetching column kernel
     int num_cu;
 };
 
@@ -609,6 +600,16 @@ static int upload_ptw(void** dev) {
 template <typename T, int N, int E>
 static int prep_ptw(void** dev) { return upload_ptw<T, N, E>(dev); }
 
+template <typename T, int N, int E>
+static int prep_ptw_compact(void** dev) {
+    constexpr int n = ptw_total<N, E>() / 4;
+    std::vector<cplx<T>> h(n > 0 ? n : 1);
+    if (n > 0) fill_ptw_compact<T, N, E>(h.data());
+    PFB_HIP_CHECK(hipMalloc(dev, sizeof(cplx<T>) * h.size()));
+    PFB_HIP_CHECK(hipMemcpy(*dev, h.data(), sizeof(cplx<T>) * h.size(), hipMemcpyHostToDevice));
+    return PFB_OK;
+}
+
 // size switch helpers -------------------------------------------------------------
 #define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 
@@ -619,6 +620,7 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     constexpr int lds_max = 160 * 1024;
     switch (H) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, FastCfg<T>::ECOL>(&ft->ptw_col);                          \
+        if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, FastCfg<T>::ECOL>(&ft->ptwc_col);             \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2<T, NN, FastCfg<T>::ECOL>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2p<T, NN, FastCfg<T>::ECOL>, \
@@ -686,7 +688,9 @@ int pow2_prepare(pfb_conv_plan* p) {
     FastTables* ft = (FastTables*)calloc(1, sizeof(FastTables));
     PFB_REQUIRE(ft != nullptr, PFB_ERR_ALLOC, "pow2_prepare: host alloc failed");
     p->fast_tables = ft;
-    ft->col_persistent = 0;   // measured slower than 2 WG/CU of the plain kernel (0.32 vs 0.24 ms at 4096^2): kept for A/B
+    // -1 = auto: the persistent prefetching kernel wins up to nx = 2048 (0.27 vs 0.33 ms at
+    // 2048^2 x 8), the plain 2-workgroup/CU kernel at 4096 (1.17 vs 1.22 ms); 0 / 1 force one
+    ft->col_persistent = -1;
     if (const char* e = getenv("PFB_COL_PERSIST")) ft->col_persistent = atoi(e) ? 1 : 0;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -700,6 +704,7 @@ void pow2_release(pfb_conv_plan* p) {
     FastTables* ft = (FastTables*)p->fast_tables;
     if (!ft) return;
     if (ft->ptw_col) (void)hipFree(ft->ptw_col);
+    if (ft->ptwc_col) (void)hipFree(ft->ptwc_col);
     if (ft->ptw_row) (void)hipFree(ft->ptw_row);
     if (ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv);
     if (ft->twM) (void)hipFree(ft->twM);
@@ -730,16 +735,17 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
     constexpr int GC = col_groups<H, E>();
     const int nblk = fast_nblocks(p->ny / 2, FastCfg<T>::NVB);
     const size_t lds = sizeof(cplx<T>) * (size_t)GC * FastCfg<T>::NVB * F::LDS_ELEMS;
-    if (ft->col_persistent) {
+    if (ft->col_persistent == 1 || (ft->col_persistent < 0 && H <= 2048)) {
         // one resident workgroup set: 8 waves per CU at 256 VGPRs
         const int nitems = nblk * nb;
         const int wg_per_cu = (8 * 64) / (GC * F::TPB) > 0 ? (8 * 64) / (GC * F::TPB) : 1;
         int grid = ft->num_cu * wg_per_cu;
         const int need = (nitems + GC - 1) / GC;
         if (grid > need) grid = need;
-        hipLaunchKernelGGL((k_col_pow2p<T, H, E>), dim3(grid), dim3(GC * F::TPB), lds, st,
+        hipLaunchKernelGGL((k_col_pow2p<T, H, E>), dim3(grid), dim3(GC * F::TPB),
+                           lds + sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1), st,
                            (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
-                           (const cplx<T>*)ft->ptw_col, nblk, nitems, p->T_elems_per_band,
+                           (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
                            p->psf_elems_per_band, band0);
         return;
     }
