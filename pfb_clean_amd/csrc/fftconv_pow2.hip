@@ -67,7 +67,7 @@ template <typename T, int L> struct InvDb {
     using C = RowCfg<T, L, true>;
     static constexpr int G = row_groups<T, L, C::E, C::GMAX>();
     static constexpr int STRIDE = L + L / 16 + 4;
-    static constexpr bool ON = (size_t)2 * G * STRIDE * sizeof(cplx<T>) + 384 <= (size_t)152 * 1024;
+    static constexpr bool ON = (size_t)(2 * G * STRIDE + L) * sizeof(cplx<T>) + 384 <= (size_t)152 * 1024;
     static constexpr int OFF = ON ? G * STRIDE : 0;
 };
 
@@ -442,13 +442,13 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
 // one parity of the inverse row transform: gathers Y[2m + PAR][i0 .. i0+G) (G*8-byte
 // pieces), LDS-transposes them to per-row order, builds the packed spectrum and runs
 // the inverse FFT; result in vv (register j <-> sample t + TPB j of IFFT_L)
-template <typename T, int L, int E, int PAR>
-__device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
+template <typename T, int L, int E, int PAR, typename PF>
+__device__ __forceinline__ void row_inv_phase(PF&& after_loads_issued, const cplx<T>* __restrict__ Tb,
                                               const cplx<T>* __restrict__ twQ,
                                               const cplx<T>* __restrict__ ptw, cplx<T>* lds0,
                                               cplx<T>* lds, int nx, int i0, int t,
                                               cplx<T> (&vv)[E]) {
-    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF, true>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
@@ -470,6 +470,11 @@ __device__ __forceinline__ void row_inv_phase(const cplx<T>* __restrict__ Tb,
         const int b = bi + k * BSTEP;
         if (b < NBP) y[k] = loadb<T, NVB>(Tp + (size_t)b * nx * NVB);    // bins of block b, row rr
     }
+    // vmcnt is in order: loads issued from here on are YOUNGER than the strided loads above,
+    // so waiting for those does not wait for these (prefetch hook of the kernel).  (Also
+    // hoisting the w_Q twiddle loads of the unpacking loop up here would keep the prefetch in
+    // flight longer, but costs 16 more live registers: measured slower, 1.01 vs 0.93 ms.)
+    after_loads_issued();
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int b = bi + k * BSTEP;
@@ -505,7 +510,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                const T* __restrict__ x, const T* __restrict__ beam,
                const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
                double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv) {
-    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF>;
+    using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF, true>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     constexpr int NT = G * TPB;
@@ -514,9 +519,11 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);                 // 3 sums * 16 waves * 8 B
-    cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem + 384);
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem + 384);          // compact twiddle table (LDS)
+    cplx<T>* lds0 = ltw + ((F::PTWC + 1) & ~1);
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* lds = lds0 + (size_t)g * STRIDE;
+    for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptw[k];   // visible after the first barrier
     // XCD-aware row-group order: with G = 4 a 128-byte line of T is shared by two row groups;
     // workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2 --
     // give THEM the two halves of a line (speed only, any mapping is correct).
@@ -531,40 +538,50 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     const int bl = blockIdx.y, band = band0 + bl;
     const cplx<T>* Tb = Tw + (size_t)band * d.T_band;
     cplx<T> vv[E], ev[E];
-    row_inv_phase<T, L, E, 0>(Tb, twQ, ptw, lds0, lds, d.nx, i0, t, ev);
-    row_inv_phase<T, L, E, 1>(Tb, twQ, ptw, lds0, lds, d.nx, i0, t, vv);
-    // z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
+    row_inv_phase<T, L, E, 0>([] {}, Tb, twQ, ltw, lds0, lds, d.nx, i0, t, ev);
+    // The kernel's phases do not overlap inside one workgroup (ablation: T loads 0.23 ms +
+    // epilogue loads 0.31 ms + FFTs 0.20 ms + rest 0.22 ms = the 1.06 ms total at 4096^2 x 8),
+    // and registers allow only one workgroup per CU: so the epilogue operands x and dot_with2
+    // are requested right after the odd-bin strided loads and arrive while that transform runs.
     const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
-    const V2* xr = reinterpret_cast<const V2*>(x + rowoff);
-    const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) : nullptr;
-    const V2* dr = dot_with ? reinterpret_cast<const V2*>(dot_with + rowoff) : nullptr;
-    const V2* dr2 = dot_with2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) : nullptr;
-    V2* orow = reinterpret_cast<V2*>(out + rowoff);
+    const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+    const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
+    const V2* dr = dot_with ? reinterpret_cast<const V2*>(dot_with + rowoff) + t : nullptr;
+    const V2* dr2 = dot_with2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) + t : nullptr;
+    V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
+    const bool dot_is_x = dot_with == x;            // PCG: <p, A p> with x = p
+    V2 xq[E], rq[E];
+    row_inv_phase<T, L, E, 1>([&] {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            xq[j] = xr[TPB * j];
+            if (dr2) rq[j] = dr2[TPB * j];
+        }
+    }, Tb, twQ, ltw, lds0, lds, d.nx, i0, t, vv);
+    // z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
     double acc[3] = {0.0, 0.0, 0.0};       // <dot_with,out>, <dot_with2,out>, <out,out>
+    const cplx<T>* tm = twM + t;
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const int n = t + TPB * j;
-        const cplx<T> zz = ev[j] + mulc(vv[j], twM[n]);
+        const cplx<T> zz = ev[j] + mulc(vv[j], tm[TPB * j]);
         V2 val;
         val.x = zz.x * scale;
         val.y = zz.y * scale;
-        if (br) { const V2 b = br[n]; val.x *= b.x; val.y *= b.y; }
-        const V2 xx = xr[n];
+        if (br) { const V2 b = br[TPB * j]; val.x *= b.x; val.y *= b.y; }
+        const V2 xx = xq[j];
         val.x += sigmainv * xx.x;
         val.y += sigmainv * xx.y;
-        orow[n] = val;
+        orow[TPB * j] = val;
         if (dr) {
-            const V2 dw = dr[n];
+            V2 dw = xx;
+            if (!dot_is_x) dw = dr[TPB * j];
             acc[0] += (double)dw.x * (double)val.x + (double)dw.y * (double)val.y;
             if (dr2) {
-                const V2 d2 = dr2[n];
+                const V2 d2 = rq[j];
                 acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
             }
             acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
         }
-        // keep at most 4 elements' worth of x/beam/dot_with/twiddle loads in flight: the
-        // scheduler otherwise hoists all 4*E loads to the top and spills
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     if (dot_with) {
         __syncthreads();
@@ -581,7 +598,7 @@ struct FastTables {            // device tables owned by the plan (stored behind
     void* ptw_col;
     void* ptwc_col;            // compact (w only) table of the column transform, copied to LDS
     void* ptw_row;             // forward row kernel (E = 16)
-    void* ptw_row_inv;         // inverse row kernel (E = 8)
+    void* ptw_row_inv;         // inverse row kernel (E = 8): COMPACT table, copied to LDS
     void* twM;                 // exp(-2 pi i n / M), n < L
     int col_persistent;        // PFB_COL_PERSIST (default: auto by size): persistent prefetching column kernel
     int num_cu;
@@ -633,7 +650,7 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     rc = PFB_ERR_UNSUPPORTED;
     switch (L) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, RowCfg<T, NN, false>::E>(&ft->ptw_row);                   \
-        if (rc == PFB_OK) rc = prep_ptw<T, NN, RowCfg<T, NN, true>::E>(&ft->ptw_row_inv);            \
+        if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, RowCfg<T, NN, true>::E>(&ft->ptw_row_inv);    \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2<T, NN, RowCfg<T, NN, false>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, RowCfg<T, NN, true>::E>, \
@@ -775,7 +792,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
-    const size_t lds = 384 + sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4) * (InvDb<T, L>::ON ? 2 : 1);
+    const size_t lds = 384 + sizeof(cplx<T>) * ((size_t)((F::PTWC + 1) & ~1) + (size_t)G * (F::LDS_ELEMS + 4) * (InvDb<T, L>::ON ? 2 : 1));
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,
                        (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam, (const T*)dot_with,
