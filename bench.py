@@ -166,10 +166,14 @@ def main():
     if napply > 0:
         conv_ms = sum(stage_ms) / napply                              # per launch group (nb bands)
         achieved = balg_band * nb / (conv_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(n, nb, args.dtype)
         roofline = {
             "bound": "hbm", "kernel": "fft-convolution (row_fwd + col + row_inv)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
+            "traffic_source": traffic_src,
+            "hbm_rate_from_traffic_GBs": None if traffic is None else round(traffic / (conv_ms * 1e-3) / 1e9, 1),
             "alg_bytes_per_launch": balg_band * nb, "launches_timed": napply,
             "ms_per_launch": round(conv_ms, 4),
             "stage_ms": {"row_fwd": round(stage_ms[0] / napply, 4),
@@ -204,6 +208,23 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(n, nb, dtype):
+    """HBM bytes per launch of the convolution kernel group, from the committed rocprofv3
+    PMC summary of THIS workload (counters cannot be read from inside the process; they are
+    collected in separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of bench.py and
+    corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        c = d.get('config', {})
+        if c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
+            return d.get('conv_group_hbm_bytes_per_launch'), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def cpu_baseline(psfhat_dev, b_dev, sigmainv, n, nband, seconds, x_gpu):
