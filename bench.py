@@ -97,11 +97,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # RCCL in production; PFB_DIST_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 path
+        dist.init_process_group(os.environ.get('PFB_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % max(ndev, 1))
+    device = torch.device('cuda', local_rank % max(ndev, 1))
 
     from pfb_clean_amd.operators.psf import PsfConvPlan
     from pfb_clean_amd.operators.hessian import HessianPsf
