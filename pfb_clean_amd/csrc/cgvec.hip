@@ -11,6 +11,7 @@
 // fused out of the convolution epilogue (fftconv*.hip).
 #include "conv_plan.hpp"
 #include <cstring>
+#include <cstdlib>
 
 namespace pfb {
 
@@ -229,6 +230,48 @@ k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__
     emit_partials<1>(acc, ws);
 }
 
+// update + direction in ONE pass (7 instead of 6 + 3 vector streams): possible because the
+// predictive line search already knows rnorm_next = rho(alpha) before the vectors are touched,
+// so beta = rho(alpha)/rho is available up front (the reference forms beta from the recomputed
+// <r',y'>; the two differ by rounding only -- the recomputed value is still what the NEXT
+// iteration uses as rnorm).  sums: <r',y'>, |x'-x|^2, |x'|^2, count(p' != 0)
+template <typename T, int V>
+__global__ void __launch_bounds__(RED_BLOCK)
+k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ p,
+                 const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
+                 const double* __restrict__ alpha_dev, T mdiv, size_t nvec, double* __restrict__ ws) {
+    const bool dead = alpha_dev[S_DEAD - S_ALPHA] != 0.0;
+    const T alpha = dead ? T(0) : (T)alpha_dev[0];
+    const T beta = (T)alpha_dev[S_BETA - S_ALPHA];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        Pack<T, V> px = ld<T, V>(x, i), pr = ld<T, V>(r, i), pp = ld<T, V>(p, i),
+                   pa = ld<T, V>(Ap, i), ox, orr;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const T xnew = px.e[e] + alpha * pp.e[e];
+            const T rnew = pr.e[e] + alpha * pa.e[e];
+            const T y = mdiv > T(0) ? rnew / mdiv : rnew;
+            ox.e[e] = xnew;
+            orr.e[e] = rnew;
+            const double d = (double)xnew - (double)px.e[e];
+            acc[0] += (double)rnew * (double)y;
+            acc[1] += d * d;
+            acc[2] += (double)xnew * (double)xnew;
+            if (!dead) {
+                const T pn = beta * pp.e[e] - y;
+                pp.e[e] = pn;
+            }
+            acc[3] += (pp.e[e] != T(0)) ? 1.0 : 0.0;
+        }
+        st<T, V>(xn, i, ox);
+        st<T, V>(rn, i, orr);
+        if (!dead) st<T, V>(p, i, pp);
+    }
+    emit_partials<4>(acc, ws);
+}
+
 // tiny scalar kernels on the device state
 __global__ void k_set_alpha(double* S) { S[S_ALPHA] = S[S_RHO] / S[S_PAP]; S[S_NBT] = 0.0; }
 // Predictive backtracking.  With M(r) = r/d linear, <r',M r'> along r' = r + a Ap is the
@@ -261,17 +304,21 @@ __global__ void k_iter_begin(double* S, double mdiv, int predict) {
     const double rho = S[S_RHO];
     double alpha = rho / S[S_PAP];
     int nbt = 0;
-    if (predict) {
+    if (predict == 1 || predict == 2) {
         const double d = mdiv > 0.0 ? mdiv : 1.0;
         const double s1 = S[S_RAP] / d, s2 = S[S_APAP] / d;
         while (rho + (2.0 * alpha * s1 + alpha * alpha * s2) > rho && nbt < 200) { alpha *= 0.75; ++nbt; }
     }
     S[S_ALPHA] = alpha;
     S[S_NBT] = (double)nbt;
+    if (predict >= 2) {                    // fused update+direction: beta from rho(alpha)
+        const double d = mdiv > 0.0 ? mdiv : 1.0;
+        S[S_BETA] = (rho + (2.0 * alpha * S[S_RAP] + alpha * alpha * S[S_APAP]) / d) / rho;
+    }
 }
-__global__ void k_iter_end(double* S) {
+__global__ void k_iter_end(double* S, int fused) {
     if (S[S_DEAD] != 0.0) return;
-    S[S_BETA] = S[S_RHON] / S[S_RHO];
+    if (!fused) S[S_BETA] = S[S_RHON] / S[S_RHO];
     S[S_RHO] = S[S_RHON];
     S[S_K] += 1.0;
     S[S_EPSP] = S[S_EPS];
@@ -438,23 +485,38 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         //   [p.Ap, r.Ap, Ap.Ap, any(p)]  and  [r'.y', |x'-x|^2, |x'|^2].
         int khost = 0;
         bool go = (1.0 > tol || 0 < minit) && 0 < maxit;
+        const char* nf = getenv("PFB_PCG_NO_FUSE_DIR");
+        const bool fuse_dir = !(nf && atoi(nf));     // A/B switch: separate update / direction kernels
         while (go) {
-            if (backtrack == 2)
+            if (backtrack == 2 || fuse_dir)
                 err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);
             else
                 err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
             if (err != PFB_OK) return err;
             if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
-            hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 1 : 0);
-            PFB_LAUNCH_VEC(T, k_pcg_update, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
-                           (const T*)rcur, (const T*)p, (const T*)Ap, xnew, rnew,
-                           (const double*)(S + S_ALPHA), mdiv);
-            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
-            if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
-            hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S);
-            { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
-            PFB_LAUNCH_VEC(T, k_pcg_dir, n, (PL{p, rcur}), p, (const T*)rcur, (const double*)(S + S_BETA), mdiv);
-            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, S + S_ANY);
+            if (fuse_dir) {
+                // needs <r,Ap>, <Ap,Ap> even without backtracking (beta comes from rho(alpha))
+                hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
+                PFB_LAUNCH_VEC(T, k_pcg_update_dir, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
+                               (const T*)rcur, p, (const T*)Ap, xnew, rnew,
+                               (const double*)(S + S_ALPHA), mdiv);
+                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
+                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws + 3 * (size_t)G_used, G_used, 1, S + S_ANY);
+                if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
+                hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
+            } else {
+                hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 1 : 0);
+                PFB_LAUNCH_VEC(T, k_pcg_update, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
+                               (const T*)rcur, (const T*)p, (const T*)Ap, xnew, rnew,
+                               (const double*)(S + S_ALPHA), mdiv);
+                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
+                if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
+                hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 0);
+                { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
+                PFB_LAUNCH_VEC(T, k_pcg_dir, n, (PL{p, rcur}), p, (const T*)rcur, (const double*)(S + S_BETA), mdiv);
+                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 1, S + S_ANY);
+            }
             ++khost;
             if (khost < minit && khost < maxit) continue;          // cannot stop yet: no need to look
             if ((err = fetch()) != PFB_OK) return err;
