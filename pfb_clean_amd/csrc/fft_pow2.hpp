@@ -191,7 +191,9 @@ template <typename T, bool INV> struct Dft<T, INV, 16> {
 // into LDS by the kernel, which takes every global load out of the passes: s_waitcnt vmcnt
 // is in-order, so a twiddle load inside a pass would force every older, deliberately
 // early-issued load (prefetch of the next operand) to complete first.
-template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0, bool SQTW = false>
+// SEQX: the NV transforms of runN share ONE LDS buffer and exchange one after the other
+// (twice the barriers per pass, NV times less LDS).
+template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0, bool SQTW = false, bool SEQX = false>
 struct RegFft {
     static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
     static_assert(!WAVE || N / E <= 64, "wave-local exchange needs the group inside one wave");
@@ -284,6 +286,24 @@ struct RegFft {
         for (int n = 0; n < NV; ++n) butterflies<INV, P>(v[n], t, ptw);
         if constexpr (P * R < N) {
             cplx<T>* lds = (DBOFF > 0 && (XCH & 1) == 0) ? lds_in + DBOFF : lds_in;
+            if constexpr (SEQX) {
+#pragma unroll
+                for (int n = 0; n < NV; ++n) {
+                    sync();                        // previous readers of `lds` are done
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        const int i = t + TPB * q;
+                        const int k = i & (P - 1);
+                        cplx<T>* wp = lds + pad((i - k) * R + k);
+#pragma unroll
+                        for (int s = 0; s < R; ++s) wp[cpad(s * P)] = v[n][q + s * NB];
+                    }
+                    sync();
+                    const cplx<T>* rp = lds + pad(t);
+#pragma unroll
+                    for (int j = 0; j < E; ++j) v[n][j] = rp[cpad(TPB * j)];
+                }
+            } else {
             if constexpr (DBOFF == 0) sync();      // previous readers of `lds` are done
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
@@ -302,6 +322,7 @@ struct RegFft {
             for (int n = 0; n < NV; ++n) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cpad(TPB * j)];
+            }
             }
             pass<INV, P * R, NV, XCH + 1>(v, lds_in, t, ptw);
         }

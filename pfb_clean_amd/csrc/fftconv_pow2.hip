@@ -341,52 +341,29 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 }
 
 // ------------------------------------------------------------------- row forward
-// one parity (even / odd output bins) of the forward row transform for G rows
-template <typename T, int L, int E, int PAR>
-__device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_in,
-                                              const typename vec2<T>::type* br_in,
-                                              const cplx<T>* __restrict__ twQ,
-                                              const cplx<T>* __restrict__ twM,
-                                              const cplx<T>* __restrict__ ptw, cplx<T>* lds0,
-                                              cplx<T>* lds, cplx<T>* __restrict__ Tb, int nx, int i0,
-                                              int t) {
-    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
+// Hermitian post-processing of one parity: the group's transform Z (registers, natural order)
+// goes to LDS, then every lane produces the NVB bins of one block for one row and the G lanes
+// of a block lane-group write one contiguous G*16-byte piece of T.
+template <typename T, int L, int E, int PAR, typename F>
+__device__ __forceinline__ void row_fwd_post(const cplx<T> (&z)[E], const cplx<T>* __restrict__ twQ,
+                                             cplx<T>* lds0, cplx<T>* lds, cplx<T>* __restrict__ Tb,
+                                             int nx, int i0, int t) {
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
-    using V2 = typename vec2<T>::type;
-    const int rr = threadIdx.x % G, bi = threadIdx.x / G;      // row in the group, block lane
+    const int rr = threadIdx.x % G, bi = threadIdx.x / G;
     const cplx<T>* zr = lds0 + (size_t)rr * STRIDE;
-    cplx<T> vv[E];
-    {
-        // z[n] = x[2n] + i x[2n+1]  (re-read per parity: an L2 hit that keeps the
-        // kernel within 128 VGPRs at 1024 threads)
-        const V2* xr = opaque(xr_in + t);
-        const V2* br = br_in ? opaque(br_in + t) : nullptr;
-        const cplx<T>* tm = twM + t;
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            V2 a = xr[TPB * j];
-            if (br) { V2 b = br[TPB * j]; a.x *= b.x; a.y *= b.y; }
-            const cplx<T> zz(a.x, a.y);
-            vv[j] = PAR ? zz * tm[TPB * j] : zz;
-        }
-    }
-    __syncthreads();                             // the previous parity's cross-row reads are done
-    F::template run<false>(vv, lds, t, ptw);
-    F::sync();                                   // own group finished the last exchange read
+    __syncthreads();                             // earlier readers of the row buffers are done
     {
         cplx<T>* wp = lds + F::pad(t);
 #pragma unroll
-        for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[j];
+        for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = z[j];
     }
     __syncthreads();
     // X[v] = 1/2 [ (Z[v] + conj Z[M-v]) - i w_Q^v (Z[v] - conj Z[M-v]) ]
     //   even v = 2m   : Z -> Ze[m mod L], Ze[(L-m) mod L]      m = 0..L
     //   odd  v = 2m+1 : Z -> Zo[m],       Zo[L-1-m]            m = 0..L-1
-    // each lane produces the NVB bins of block b for ONE row: 16 bytes; the G lanes of a
-    // block lane-group cover rows i0..i0+G-1 -> one contiguous G*16-byte piece of T[b]
     constexpr int NVB = FastCfg<T>::NVB;
     constexpr int NBE = (L + NVB) / NVB;
     constexpr int NBP = PAR ? L / NVB : NBE;                 // blocks of this parity
@@ -408,7 +385,6 @@ __device__ __forceinline__ void row_fwd_phase(const typename vec2<T>::type* xr_i
         }
         storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
     }
-    // the next FFT's first exchange starts with a barrier, protecting these LDS reads
 }
 
 template <typename T, int L, int E>
@@ -416,12 +392,12 @@ __global__ void __launch_bounds__((row_groups<T, L, E, RowCfg<T, L, false>::GMAX
 k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw,
                const cplx<T>* __restrict__ twQ, const cplx<T>* __restrict__ twM,
                const cplx<T>* __restrict__ ptw, FastDims d, int band0) {
-    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
+    // the even-bin and odd-bin transforms advance together (NV = 2) through ONE row buffer
+    // (SEQX): the image row is read from HBM once instead of once per parity
+    using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE, 0, false, true>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
-    constexpr int NT = G * TPB;
     constexpr int STRIDE = F::LDS_ELEMS + 4;
-    constexpr int HP = G / 2;                    // row pairs
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem);
@@ -430,12 +406,24 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
     const int i0 = blockIdx.x * G;
     const int bl = blockIdx.y, band = band0 + bl;
     const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
-    const V2* xr = reinterpret_cast<const V2*>(x + rowoff);
-    const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) : nullptr;
-
+    const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+    const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
     cplx<T>* Tb = Tw + (size_t)band * d.T_band;
-    row_fwd_phase<T, L, E, 0>(xr, br, twQ, twM, ptw, lds0, lds, Tb, d.nx, i0, t);
-    row_fwd_phase<T, L, E, 1>(xr, br, twQ, twM, ptw, lds0, lds, Tb, d.nx, i0, t);
+
+    cplx<T> vv[2][E];
+    {
+        const cplx<T>* tm = twM + t;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            V2 a = xr[TPB * j];
+            if (br) { V2 b = br[TPB * j]; a.x *= b.x; a.y *= b.y; }
+            vv[0][j] = cplx<T>(a.x, a.y);                    // z[n] = x[2n] + i x[2n+1]
+            vv[1][j] = vv[0][j] * tm[TPB * j];               // z .* w_M^n  (odd bins)
+        }
+    }
+    F::template runN<false, 2>(vv, lds, t, ptw);
+    row_fwd_post<T, L, E, 0, F>(vv[0], twQ, lds0, lds, Tb, d.nx, i0, t);
+    row_fwd_post<T, L, E, 1, F>(vv[1], twQ, lds0, lds, Tb, d.nx, i0, t);
 }
 
 // ------------------------------------------------------------------- row inverse
