@@ -115,6 +115,27 @@ def pcg(A, b, x0=None, M=None, tol=1e-5, maxit=500, minit=100, verbosity=1,
     return x, r
 
 
+def cg(A, b, x0=None, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
+    """pcg.py:12-50: plain CG, eps = <r,r> (unnormalised), in-place x/r updates."""
+    x = np.zeros(b.shape, dtype=b.dtype) if x0 is None else x0.copy()
+    r = A(x) - b
+    p = -r
+    rnorm = np.vdot(r, r)
+    eps, k = rnorm, 0
+    while eps > tol and k < maxit:
+        Ap = A(p)
+        alpha = rnorm / np.vdot(p, Ap)
+        x += alpha * p
+        r += alpha * Ap
+        rnorm_next = np.vdot(r, r)
+        beta = rnorm_next / rnorm
+        p = beta * p - r
+        rnorm = rnorm_next
+        eps = rnorm
+        k += 1
+    return x
+
+
 def pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, sigmainv, cgopts):
     """pcg.py:243-360 without the dask wrapping: independent PCG per band with
     A = _hessian_psf_slice(psfhat[k], beam[k], sigmainv), M = x/sigmainv."""

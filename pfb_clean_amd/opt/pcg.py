@@ -257,6 +257,50 @@ def _pcg_generic(A, b, x0, M, tol, maxit, minit, verbosity, report_freq, backtra
     return host(x), host(r)
 
 
+def cg(A, b, x0=None, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
+    """pfb/opt/pcg.py:12-50 -- the plain CG variant (no preconditioner, no backtracking,
+    stopping rule `eps = <r,r> > tol`, unused by the live workers).  Vector work and
+    reductions in the HIP kernels; A is called with the array kind of `b`."""
+    lib = _lib.load()
+    as_numpy = _dev.is_numpy(b)
+    bd = _dev.to_dev(b).contiguous()
+    dt, n = bd.dtype, bd.numel()
+    code = _dev.code(dt)
+    ws, out = _dev.scratch()
+
+    def host(t):
+        return t.cpu().numpy() if as_numpy else t
+
+    def dot(u, v):
+        _lib.check(lib.pfb_dot(code, _dev.ptr(u), _dev.ptr(v), n, _dev.ptr(out), _dev.ptr(ws), _dev.stream()))
+        return out[0].item()
+
+    def axpby(a, u, bb, v):
+        _lib.check(lib.pfb_axpby(code, float(a), _dev.ptr(u), float(bb), _dev.ptr(v), n, _dev.stream()))
+
+    x = torch.zeros_like(bd) if x0 is None else _dev.to_dev(x0, dt).contiguous().clone()
+    r = _dev.to_dev(A(host(x)), dt).contiguous().clone()
+    axpby(-1.0, bd, 1.0, r)                          # r = A(x) - b
+    p = r.clone()
+    axpby(0.0, r, -1.0, p)                           # p = -r
+    rnorm = dot(r, r)
+    eps, k = rnorm, 0
+    while eps > tol and k < maxit:
+        Ap = _dev.to_dev(A(host(p)), dt).contiguous()
+        alpha = rnorm / dot(p, Ap)
+        axpby(alpha, p, 1.0, x)
+        axpby(alpha, Ap, 1.0, r)
+        rnorm_next = dot(r, r)
+        beta = rnorm_next / rnorm
+        axpby(-1.0, r, beta, p)                      # p = beta*p - r
+        rnorm = rnorm_next
+        eps = rnorm
+        k += 1
+    if k >= maxit and verbosity:
+        print(f"Max iters reached eps = {eps}", file=sys.stderr)
+    return host(x)
+
+
 def pcg_psf(psfhat, b, x0, beam, lastsize, nthreads, sigmainv, cgopts, compute=True):
     """pfb/opt/pcg.py:310-360 (+ _pcg_psf_impl :243-291): independent PCG per band with
     A = _hessian_psf_slice(psfhat[k], beam[k], sigmainv) and M = x/sigmainv when

@@ -120,3 +120,32 @@ def test_fwdbwd_composition_config4_reduced():
                                    tol=0.0, maxit=12, positivity=1, verbosity=0)
     assert np.abs(xb.cpu().numpy() - xb_ref).max() < 1e-8 * np.abs(xb_ref).max()
     assert np.abs(vb.cpu().numpy() - vb_ref).max() < 1e-8 * np.abs(vb_ref).max()
+
+
+def test_plain_cg_and_psfhat_producer():
+    """pcg.py:12-50 (cg) against the oracle; gridder.py:712-714 (psfhat producer) against the
+    oracle's scipy version and through a convolution with a centred delta PSF (= identity)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.opt.pcg import cg
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    from pfb_clean_amd.operators.fft import psfhat_from_psf
+    from pfb_clean_amd.operators.psf import psf_convolve_slice
+    rng = np.random.default_rng(21)
+    nb, nx, ny = 1, 64, 48
+    psfhat = _psd_psfhat(rng, nb, 2 * nx, 2 * ny)
+    b = rng.standard_normal((nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(psfhat[0], 2 * ny, b.shape, np.float64)
+
+    def oA(v):
+        return ofc._hessian_psf_slice(xpad, xhat, xout, psfhat[0], None, 2 * ny, v, sigmainv=0.05)
+    ref = osv.cg(oA, b, None, tol=1e-12, maxit=25)
+    A = HessianPsf(psfhat[0], nx, ny, 2 * ny, sigmainv=0.05)
+    x = cg(A, b, None, tol=1e-12, maxit=25, verbosity=0)
+    assert np.abs(x - ref).max() < 1e-9 * np.abs(ref).max()
+    psf = rng.standard_normal((2, 32, 40))
+    assert np.abs(psfhat_from_psf(psf) - ofc.psfhat_from_psf(psf)).max() < 1e-12
+    delta = np.zeros((2 * nx, 2 * ny))
+    delta[nx, ny] = 1.0                                   # centred unit PSF -> identity
+    y = psf_convolve_slice(None, None, None, psfhat_from_psf(delta), 2 * ny, b)
+    assert np.abs(y - b).max() < 1e-13
