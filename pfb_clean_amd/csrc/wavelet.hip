@@ -22,8 +22,10 @@ namespace pfb {
 
 constexpr int MAXF = 18;        // db9
 constexpr int MAXLEV = 12;
-constexpr int TA = 16;          // analysis: output tile edge (coefficients per quadrant)
-constexpr int TS = 32;          // synthesis: output tile edge (image pixels)
+// tile edges: analysis = coefficients per quadrant and edge, synthesis = image pixels per edge
+template <typename T> struct Tile;
+template <> struct Tile<float>  { static constexpr int TA = 32; static constexpr int TS = 64; };
+template <> struct Tile<double> { static constexpr int TA = 16; static constexpr int TS = 32; };
 
 template <typename T> struct Filt { T lo[MAXF]; T hi[MAXF]; int F; };
 
@@ -80,16 +82,19 @@ k_transpose(const T* __restrict__ src, size_t src_band, int ls, T* __restrict__ 
 // in    : (nxin, nyin) row-major, ld = ldin
 // coeffs: this level's block origin, ld = ldc; quadrants [0:Cy | Cy:2Cy] x [0:Cx | Cx:2Cx]
 // approx: optional (Cx, Cy) row-major copy of the LL quadrant transposed (next level input)
-template <typename T>
+// F (filter length) and TA (output tile edge per quadrant) are compile-time: the staging loop
+// is fully unrolled so that ALL global loads of a thread are in flight before the first LDS
+// store (a rolled load-wait-store loop pays the HBM latency once per trip: 104 us -> see
+// DESIGN.md), and the tap loops are unrolled FMA chains.
+template <typename T, int F, int TA>
 __global__ void __launch_bounds__(256)
 k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int nyin,
             T* __restrict__ coeffs, size_t c_band, int ldc, int Cx, int Cy,
             T* __restrict__ approx, size_t a_band, Filt<T> f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int F = f.F;
-    const int NI = 2 * TA + F - 2;            // input samples per tile edge
-    const int SA = NI + 1;                    // LDS strides (odd -> conflict-free columns)
-    const int SB = 2 * TA + 1;
+    constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
+    constexpr int SA = NI + 1;                // LDS strides (odd -> conflict-free columns)
+    constexpr int SB = 2 * TA + 1;
     T* A = reinterpret_cast<T*>(smem);        // [NI][SA]   input tile  A[lx][ly]
     T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
     T* LL = B + NI * SB;                      // [TA][TA+1] LL quadrant for the approx copy
@@ -97,47 +102,60 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
     T* dst = coeffs + (size_t)blockIdx.z * c_band;
     const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
     const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
+    T lo[F], hi[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { lo[j] = f.lo[j]; hi[j] = f.hi[j]; }
     // 1. stage the input tile (zero extension outside the signal)
-    for (int e = threadIdx.x; e < NI * NI; e += blockDim.x) {
+    constexpr int NLD = (NI * NI + 255) / 256;
+    T stage[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
         const int lx = e / NI, ly = e - lx * NI;
         const int gx = gx0 + lx, gy = gy0 + ly;
         T v = 0;
-        if (gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
-        A[lx * SA + ly] = v;
+        if (e < NI * NI && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
+        stage[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int lx = e / NI, ly = e - lx * NI;
+        if (e < NI * NI) A[lx * SA + ly] = stage[k];
     }
     __syncthreads();
     // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
-    for (int e = threadIdx.x; e < NI * 2 * TA; e += blockDim.x) {
-        const int lx = e / (2 * TA), q = e - lx * (2 * TA);
-        const bool hi = q >= TA;
-        const int qq = hi ? q - TA : q;
-        const T* flt = hi ? f.hi : f.lo;
+    for (int e = threadIdx.x; e < NI * TA; e += 256) {
+        const int lx = e / TA, qq = e - lx * TA;
         const T* a = A + lx * SA + 2 * qq + F - 1;
-        T s = 0;
-        for (int j = 0; j < F; ++j) s += flt[j] * a[-j];
-        B[lx * SB + q] = s;
+        T sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) { const T v = a[-j]; sl += lo[j] * v; sh += hi[j] * v; }
+        B[lx * SB + qq] = sl;
+        B[lx * SB + TA + qq] = sh;
     }
     __syncthreads();
-    // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c < 2TA (x coefficient)
-    for (int e = threadIdx.x; e < 2 * TA * 2 * TA; e += blockDim.x) {
-        const int r = e / (2 * TA), c = e - r * (2 * TA);
-        const bool hix = c >= TA;
-        const int cc = hix ? c - TA : c;
-        const T* flt = hix ? f.hi : f.lo;
+    // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c (x coefficient) lo & hi
+    for (int e = threadIdx.x; e < 2 * TA * TA; e += 256) {
+        const int r = e / TA, cc = e - r * TA;
         const T* b = B + (2 * cc + F - 1) * SB + r;
-        T s = 0;
-        for (int j = 0; j < F; ++j) s += flt[j] * b[-j * SB];
+        T sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) { const T v = b[-j * SB]; sl += lo[j] * v; sh += hi[j] * v; }
         const bool hiy = r >= TA;
         const int rr = hiy ? r - TA : r;
         const int gy = oy0 + rr, gx = ox0 + cc;
-        if (gy < Cy && gx < Cx)
-            dst[(size_t)((hiy ? Cy : 0) + gy) * ldc + (hix ? Cx : 0) + gx] = s;
-        if (!hiy && !hix) LL[cc * (TA + 1) + rr] = s;
+        if (gy < Cy && gx < Cx) {
+            T* row = dst + (size_t)((hiy ? Cy : 0) + gy) * ldc;
+            row[gx] = sl;
+            row[Cx + gx] = sh;
+        }
+        if (!hiy) LL[cc * (TA + 1) + rr] = sl;
     }
     if (approx) {
         __syncthreads();
         T* ap = approx + (size_t)blockIdx.z * a_band;
-        for (int e = threadIdx.x; e < TA * TA; e += blockDim.x) {
+        for (int e = threadIdx.x; e < TA * TA; e += 256) {
             const int cc = e / TA, rr = e - cc * TA;           // rr (y) fastest: coalesced
             if (ox0 + cc < Cx && oy0 + rr < Cy) ap[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
         }
@@ -149,16 +167,16 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
 // prev   : if non-null, the approx quadrant is prev[c][r] (previous level's image,
 //          row-major ld = ldp) instead of coeffs[r][c]      (wavelets.py:303-309)
 // out    : image (nxw, nyw) row-major ld = ldo; ACC adds (sum over bases, psi.py:252)
-template <typename T, bool ACC>
+template <typename T, int F, int TS, bool ACC>
 __global__ void __launch_bounds__(256)
 k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int nay,
              const T* __restrict__ prev, size_t p_band, int ldp,
              T* __restrict__ out, size_t o_band, int ldo, int nxw, int nyw, Filt<T> f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int F = f.F, h = F / 2;
-    const int NC = TS / 2 + h - 1;            // coefficients needed per half and tile edge
-    const int SC = 2 * NC + 1;
-    const int ST = TS + 1;
+    constexpr int h = F / 2;
+    constexpr int NC = TS / 2 + h - 1;        // coefficients needed per half and tile edge
+    constexpr int SC = 2 * NC + 1;
+    constexpr int ST = TS + 1;
     T* C = reinterpret_cast<T*>(smem);        // [2NC][SC]  C[ry][cx]  (lo|hi in both)
     T* Tm = C + 2 * NC * SC;                  // [2NC][ST]  after the x pass  Tm[ry][ox]
     const T* src = coeffs + (size_t)blockIdx.z * c_band;
@@ -166,42 +184,85 @@ k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int 
     T* dst = out + (size_t)blockIdx.z * o_band;
     const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
     const int mx0 = ix0 / 2, my0 = iy0 / 2;
-    // 1. stage coefficients; rows/cols beyond (nay, nax) are only used by cropped outputs
-    for (int e = threadIdx.x; e < 2 * NC * 2 * NC; e += blockDim.x) {
-        int ry, cx;
-        if (pv) { cx = e / (2 * NC); ry = e - cx * (2 * NC); }      // ry fastest: prev is read along y
-        else    { ry = e / (2 * NC); cx = e - ry * (2 * NC); }
+    T lo[F], hi[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { lo[j] = f.lo[j]; hi[j] = f.hi[j]; }
+    // 1. stage coefficients (all loads first); rows/cols beyond (nay, nax) are only used by
+    //    cropped outputs.  coeffs are read row-wise (cx fastest), prev column-wise (ry fastest).
+    constexpr int NE = 4 * NC * NC;
+    constexpr int NLD = (NE + 255) / 256;
+    T stage[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
         const bool hy = ry >= NC, hx = cx >= NC;
         const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
         T v = 0;
-        if (gy < nay && gx < nax) {
-            if (pv && !hy && !hx) v = pv[(size_t)gx * ldp + gy];
-            else v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
+            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+        stage[k] = v;
+    }
+    constexpr int NLP = (NC * NC + 255) / 256;
+    T stagep[NLP];
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;              // ry fastest: prev is read along y
+            const int gy = my0 + ry, gx = mx0 + cx;
+            T v = 0;
+            if (e < NC * NC && gy < nay && gx < nax) v = pv[(size_t)gx * ldp + gy];
+            stagep[k] = v;
         }
-        C[ry * SC + cx] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
+    }
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;
+            if (e < NC * NC) C[ry * SC + cx] = stagep[k];
+        }
     }
     __syncthreads();
     // 2. x pass: Tm[ry][ox] = sum_j lo[2j+p] C[ry][m+h-1-j] + sum_j hi[2j+p] C[ry][NC+m+h-1-j]
-    for (int e = threadIdx.x; e < 2 * NC * TS; e += blockDim.x) {
-        const int ry = e / TS, ox = e - ry * TS;
-        const int m = ox >> 1, p = ox & 1;
+    //    (one thread makes the even/odd output pair from the same h taps)
+    for (int e = threadIdx.x; e < 2 * NC * (TS / 2); e += 256) {
+        const int ry = e / (TS / 2), m = e - ry * (TS / 2);
         const T* c = C + ry * SC + m + h - 1;
-        T sl = 0, sh = 0;
-        for (int j = 0; j < h; ++j) { sl += f.lo[2 * j + p] * c[-j]; sh += f.hi[2 * j + p] * c[NC - j]; }
-        Tm[ry * ST + ox] = sl + sh;
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = c[-j], d = c[NC - j];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        Tm[ry * ST + 2 * m] = sl0 + sh0;
+        Tm[ry * ST + 2 * m + 1] = sl1 + sh1;
     }
     __syncthreads();
-    // 3. y pass + store (iy fastest)
-    for (int e = threadIdx.x; e < TS * TS; e += blockDim.x) {
-        const int ox = e / TS, oy = e - ox * TS;
-        const int m = oy >> 1, p = oy & 1;
+    // 3. y pass + store (iy fastest); a thread makes the pair (2m, 2m+1) of one image row
+    for (int e = threadIdx.x; e < TS * (TS / 2); e += 256) {
+        const int ox = e / (TS / 2), m = e - ox * (TS / 2);
         const T* t = Tm + (m + h - 1) * ST + ox;
-        T sl = 0, sh = 0;
-        for (int j = 0; j < h; ++j) { sl += f.lo[2 * j + p] * t[-j * ST]; sh += f.hi[2 * j + p] * t[(NC - j) * ST]; }
-        const int gx = ix0 + ox, gy = iy0 + oy;
-        if (gx < nxw && gy < nyw) {
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = t[-j * ST], d = t[(NC - j) * ST];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        const int gx = ix0 + ox, gy = iy0 + 2 * m;
+        if (gx < nxw) {
             T* q = dst + (size_t)gx * ldo + gy;
-            if (ACC) *q += sl + sh; else *q = sl + sh;
+            if (gy < nyw)     { if (ACC) q[0] += sl0 + sh0; else q[0] = sl0 + sh0; }
+            if (gy + 1 < nyw) { if (ACC) q[1] += sl1 + sh1; else q[1] = sl1 + sh1; }
         }
     }
 }
@@ -319,13 +380,53 @@ static Filt<T> make_filt(const BasisInfo& b, int lo_idx, int hi_idx) {
 
 template <typename T>
 static size_t dwt_lds(int F) {
+    constexpr int TA = Tile<T>::TA;
     const int NI = 2 * TA + F - 2;
     return sizeof(T) * ((size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1) + (size_t)TA * (TA + 1));
 }
 template <typename T>
 static size_t idwt_lds(int F) {
+    constexpr int TS = Tile<T>::TS;
     const int NC = TS / 2 + F / 2 - 1;
     return sizeof(T) * ((size_t)2 * NC * (2 * NC + 1) + (size_t)2 * NC * (TS + 1));
+}
+
+#define PFB_FOR_F(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+
+template <typename T>
+static void launch_dwt(int F, dim3 grid, size_t lds, hipStream_t st, const T* in, size_t in_band, int ldin,
+                       int nxin, int nyin, T* blk, size_t c_band, int ldc, int Cx, int Cy, T* approx,
+                       size_t a_band, const Filt<T>& f) {
+    switch (F) {
+#define X(FF) case FF: hipLaunchKernelGGL((k_dwt_level<T, FF, Tile<T>::TA>), grid, dim3(256), lds, st, in, in_band, \
+                                          ldin, nxin, nyin, blk, c_band, ldc, Cx, Cy, approx, a_band, f); break;
+        PFB_FOR_F(X)
+#undef X
+        default: break;
+    }
+}
+template <typename T, bool ACC>
+static void launch_idwt(int F, dim3 grid, size_t lds, hipStream_t st, const T* blk, size_t c_band, int ldc,
+                        int nax, int nay, const T* prev, size_t p_band, int ldp, T* out, size_t o_band, int ldo,
+                        int nxw, int nyw, const Filt<T>& f) {
+    switch (F) {
+#define X(FF) case FF: hipLaunchKernelGGL((k_idwt_level<T, FF, Tile<T>::TS, ACC>), grid, dim3(256), lds, st, blk, \
+                                          c_band, ldc, nax, nay, prev, p_band, ldp, out, o_band, ldo, nxw, nyw, f); break;
+        PFB_FOR_F(X)
+#undef X
+        default: break;
+    }
+}
+template <typename T>
+static int set_wavelet_lds_limits() {
+    const int lds_max = 160 * 1024;
+#define X(FF) \
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_dwt_level<T, FF, Tile<T>::TA>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); \
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<T, FF, Tile<T>::TS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); \
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<T, FF, Tile<T>::TS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_FOR_F(X)
+#undef X
+    return PFB_OK;
 }
 
 template <typename T>
@@ -351,9 +452,10 @@ static int psi_dot_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st) {
             T* blk = ab + (size_t)L.lowy * p->Nxmax + L.lowx;
             const bool last = l == p->nlevel - 1;
             T* approx = last ? nullptr : (T*)p->scratch[l & 1];
+            constexpr int TA = Tile<T>::TA;
             dim3 grid((L.Cx + TA - 1) / TA, (L.Cy + TA - 1) / TA, p->nband);
-            hipLaunchKernelGGL((k_dwt_level<T>), grid, dim3(256), dwt_lds<T>(b.F), st, in, in_band, ldin,
-                               L.nxin, L.nyin, blk, aband, p->Nxmax, L.Cx, L.Cy, approx, p->scratch_band, f);
+            launch_dwt<T>(b.F, grid, dwt_lds<T>(b.F), st, in, in_band, ldin, L.nxin, L.nyin, blk, aband,
+                          p->Nxmax, L.Cx, L.Cy, approx, p->scratch_band, f);
             in = approx;
             in_band = p->scratch_band;
             ldin = L.Cy;
@@ -395,13 +497,14 @@ static int psi_hdot_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
             const int nxw = finest ? (L.nxo < p->nx ? L.nxo : p->nx) : L.nxo;
             const int nyw = finest ? (L.nyo < p->ny ? L.nyo : p->ny) : L.nyo;
             const int ldo = finest ? p->ny : L.nyo;
+            constexpr int TS = Tile<T>::TS;
             dim3 grid((nxw + TS - 1) / TS, (nyw + TS - 1) / TS, p->nband);
             if (finest && !first)
-                hipLaunchKernelGGL((k_idwt_level<T, true>), grid, dim3(256), idwt_lds<T>(b.F), st, blk, aband,
-                                   p->Nxmax, L.Cx, L.Cy, prev, p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
+                launch_idwt<T, true>(b.F, grid, idwt_lds<T>(b.F), st, blk, aband, p->Nxmax, L.Cx, L.Cy, prev,
+                                     p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
             else
-                hipLaunchKernelGGL((k_idwt_level<T, false>), grid, dim3(256), idwt_lds<T>(b.F), st, blk, aband,
-                                   p->Nxmax, L.Cx, L.Cy, prev, p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
+                launch_idwt<T, false>(b.F, grid, idwt_lds<T>(b.F), st, blk, aband, p->Nxmax, L.Cx, L.Cy, prev,
+                                      p->scratch_band, ldp, out, o_band, ldo, nxw, nyw, f);
             prev = out;
             ldp = ldo;
         }
@@ -502,13 +605,10 @@ int pfb_psi_plan_create(int nband, int nx, int ny, int nbasis, const int* basis_
             return PFB_ERR_ALLOC;
         }
     }
-    const int lds_max = 160 * 1024;
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_dwt_level<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_dwt_level<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_idwt_level<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    {
+        int rc = dtype == PFB_F32 ? set_wavelet_lds_limits<float>() : set_wavelet_lds_limits<double>();
+        if (rc != PFB_OK) { pfb_psi_plan_destroy(p); return rc; }
+    }
     *plan = p;
     return PFB_OK;
 }
