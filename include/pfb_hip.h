@@ -202,6 +202,14 @@ int pfb_psi_hdot(pfb_psi_plan* plan, const void* alpha, void* xo, void* stream);
 int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight,
                     double lam, double sigma, int nband, size_t nper,
                     void* vp_out, void* stream);
+/* The same update with the bands sharded over GPUs: pfb_dual_bandsum writes the
+ * LOCAL band sum of vtilde = vp + sigma v into sum_out (nper values); the caller all-reduces
+ * that plane (RCCL, bandwidth bound) and pfb_dual_apply finishes with the GLOBAL sum. */
+int pfb_dual_bandsum(int dtype, const void* vp, const void* v, double sigma, int nband,
+                     size_t nper, void* sum_out, void* stream);
+int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in,
+                   double lam, double sigma, int nband, size_t nper, void* vp_out, void* stream);
+
 /* pfb/prox/prox_21m.py:31-61 prox_21m_numba */
 int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight,
                  double lam, double sigma, int nband, size_t nper, void* stream);

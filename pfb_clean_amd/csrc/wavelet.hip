@@ -300,6 +300,43 @@ k_dual_update(const T* vp, T* __restrict__ v, const T* __restrict__ w, T lam, T 
     }
 }
 
+// Band-sharded dual update (bands split over GPUs): phase 1 forms the LOCAL band sum of
+// vtilde = vp + sigma v per coefficient; after an all-reduce(sum) of that plane over the
+// ranks, phase 2 applies the same soft threshold with the GLOBAL sum (prox_21m.py:95-103).
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dual_bandsum(const T* __restrict__ vp, const T* __restrict__ v, T sigma, int nband, size_t nper,
+               T* __restrict__ sum_out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
+         i += (size_t)gridDim.x * blockDim.x) {
+        T sum = 0;
+        for (int b = 0; b < nband; ++b) sum += vp[(size_t)b * nper + i] + sigma * v[(size_t)b * nper + i];
+        sum_out[i] = sum;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dual_apply(const T* vp, T* __restrict__ v, const T* __restrict__ w, const T* __restrict__ sum_in,
+             T lam, T sigma, int nband, size_t nper, T* vp_out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const T a = fabs(sum_in[i] / sigma);
+        T fac = 1;
+        if (a != T(0)) {
+            const T soft = fmax(a - lam * w[i] / sigma, T(0));
+            fac = T(1) - soft / a;
+        }
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * nper + i;
+            const T vpk = vp[k];
+            const T vt = vpk + sigma * v[k];
+            const T vn = (a != T(0)) ? vt * fac : vt;
+            v[k] = vn;
+            if (vp_out) vp_out[k] = T(2) * vn - vpk;
+        }
+    }
+}
+
 // prox_21m_numba (prox_21m.py:31-61)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -650,6 +687,36 @@ int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight, doub
     else
         hipLaunchKernelGGL((k_dual_update<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
                            (double*)v, (const double*)weight, lam, sigma, nband, nper, (double*)vp_out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+int pfb_dual_bandsum(int dtype, const void* vp, const void* v, double sigma, int nband, size_t nper,
+                     void* sum_out, void* stream) {
+    PFB_REQUIRE(vp && v && sum_out && nband > 0, PFB_ERR_INVALID, "dual_bandsum: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_dual_bandsum<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
+                           (const float*)v, (float)sigma, nband, nper, (float*)sum_out);
+    else
+        hipLaunchKernelGGL((k_dual_bandsum<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
+                           (const double*)v, sigma, nband, nper, (double*)sum_out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in, double lam,
+                   double sigma, int nband, size_t nper, void* vp_out, void* stream) {
+    PFB_REQUIRE(vp && v && weight && sum_in && nband > 0, PFB_ERR_INVALID, "dual_apply: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_dual_apply<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
+                           (float*)v, (const float*)weight, (const float*)sum_in, (float)lam, (float)sigma,
+                           nband, nper, (float*)vp_out);
+    else
+        hipLaunchKernelGGL((k_dual_apply<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
+                           (double*)v, (const double*)weight, (const double*)sum_in, lam, sigma, nband, nper,
+                           (double*)vp_out);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }

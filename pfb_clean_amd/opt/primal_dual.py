@@ -16,6 +16,12 @@ operator (Psi.hdot), the 5th `psi` the ANALYSIS operator (Psi.dot) at the call s
 (workers/spotless.py:268-269); `prox` is accepted and unused.  Like the reference the
 iteration updates `x` and `v` IN PLACE and returns them.  Where the reference drops into
 pdb (x all zero, NaN eps) this returns with the state as is and a warning.
+
+Extension `group`: a torch.distributed process group over which the BAND axis is sharded
+(SURVEY 8e).  x, v, grad then hold this rank's bands; the band sum inside the dual update is
+all-reduced as one (nbasis, nymax, nxmax) plane per iteration, the norm_diff sums and the
+any(x) flag as three scalars, and positivity=2 (a pixel is zeroed in EVERY band if it is
+non-positive in ANY band) all-reduces its mask.  Every rank takes the same decisions.
 """
 import math
 import sys
@@ -29,8 +35,11 @@ from ..prox.prox_21m import dual_update_numba
 
 def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, grad,
                           nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000, positivity=1,
-                          report_freq=10, gamma=1.0, verbosity=1, maxreweight=50):
+                          report_freq=10, gamma=1.0, verbosity=1, maxreweight=50, group=None):
     lib = _lib.load()
+    if group is not None:
+        import torch.distributed as dist
+        pg = None if group is True else group
     as_numpy = _dev.is_numpy(x)
     xd = _dev.to_dev(x).contiguous()
     vd = _dev.to_dev(v, xd.dtype).contiguous()
@@ -58,14 +67,26 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     k = 0
     for k in range(maxit):
         psi(xp, vd)                                                      # :135
-        dual_update_numba(vp, vd, lam, sigma=sigma, weight=w, vp_out=vp)  # :136-137
+        dual_update_numba(vp, vd, lam, sigma=sigma, weight=w, vp_out=vp,  # :136-137
+                          group=group)
         psiH(vp, xout)                                                   # :138
         g = grad(host(xp))                                               # :139
         gd = _dev.to_dev(g, dt).contiguous()
         _lib.check(lib.pfb_pd_primal_update(code, _dev.ptr(xp), _dev.ptr(xout), _dev.ptr(gd),
-                                            float(tau), int(positivity), nband, npix,
+                                            float(tau),
+                                            0 if (group is not None and positivity == 2)
+                                            else int(positivity), nband, npix,
                                             _dev.ptr(xd), _dev.ptr(out), _dev.ptr(ws),
                                             _dev.stream()))              # :140-146
+        if group is not None:
+            if positivity == 2:
+                bad = (xd <= 0).any(dim=0).to(torch.uint8)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=pg)
+                xd.mul_((1 - bad).to(dt)[None])
+                _lib.check(lib.pfb_norm_diff_sums(code, _dev.ptr(xd), _dev.ptr(xp), xd.numel(),
+                                                  _dev.ptr(out), _dev.ptr(ws), _dev.stream()))
+                out[2] = (xd != 0).any().to(out.dtype)
+            dist.all_reduce(out[:3], op=dist.ReduceOp.SUM, group=pg)
         num, den, anyx = out[:3].tolist()
         if anyx:
             eps = math.sqrt(num / (1e-12 + den))

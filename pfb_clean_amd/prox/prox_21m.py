@@ -56,9 +56,14 @@ def prox_21m_numba(v, result, lam, sigma=1.0, weight=None):
     return _writeback(result, rd)
 
 
-def dual_update_numba(vp, v, lam, sigma=1.0, weight=None, vp_out=None):
+def dual_update_numba(vp, v, lam, sigma=1.0, weight=None, vp_out=None, group=None):
     """In place on v.  vp_out (extension): also receives 2*v_new - vp, the next statement
-    of primal_dual_optimised (primal_dual.py:137), saving one pass over the cube."""
+    of primal_dual_optimised (primal_dual.py:137), saving one pass over the cube.
+    group (extension): a torch.distributed process group over which the BAND axis is sharded;
+    the band sum of prox_21m.py:99 then becomes local sum -> all-reduce of the
+    (nbasis, nymax, nxmax) plane (RCCL) -> apply (GPU tensors only)."""
+    if group is not None:
+        return _dual_update_sharded(vp, v, lam, sigma, weight, vp_out, group)
     lib = _lib.load()
     direct = isinstance(v, torch.Tensor) and v.is_cuda and v.is_contiguous()
     vd, wd, nband, nper = _prep(v, weight)
@@ -71,6 +76,24 @@ def dual_update_numba(vp, v, lam, sigma=1.0, weight=None, vp_out=None):
                                    float(lam), float(sigma), nband, nper,
                                    _dev.ptr(vp_out) if vp_out is not None else None, _dev.stream()))
     return _writeback(v, vd)
+
+
+def _dual_update_sharded(vp, v, lam, sigma, weight, vp_out, group):
+    import torch.distributed as dist
+    lib = _lib.load()
+    if not (isinstance(v, torch.Tensor) and v.is_cuda and v.is_contiguous()):
+        raise TypeError("band-sharded dual update works on contiguous GPU tensors")
+    vd, wd, nband, nper = _prep(v, weight)
+    vpd = _dev.to_dev(vp, vd.dtype).contiguous()
+    plane = torch.empty(vd.shape[1:], dtype=vd.dtype, device=vd.device)
+    code = _dev.code(vd.dtype)
+    _lib.check(lib.pfb_dual_bandsum(code, _dev.ptr(vpd), _dev.ptr(vd), float(sigma), nband, nper,
+                                    _dev.ptr(plane), _dev.stream()))
+    dist.all_reduce(plane, op=dist.ReduceOp.SUM, group=None if group is True else group)
+    _lib.check(lib.pfb_dual_apply(code, _dev.ptr(vpd), _dev.ptr(vd), _dev.ptr(wd), _dev.ptr(plane),
+                                  float(lam), float(sigma), nband, nper,
+                                  _dev.ptr(vp_out) if vp_out is not None else None, _dev.stream()))
+    return v
 
 
 def prox_21m(v, sigma, weight=1.0, axis=0):

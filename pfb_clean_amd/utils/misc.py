@@ -34,12 +34,19 @@ def norm_diff(x, xp):
     return math.sqrt(num / (1e-12 + den))
 
 
-def l1reweight_func(psiH, outvar, rmsfactor, rms_comps, model, alpha=4):
+def l1reweight_func(psiH, outvar, rmsfactor, rms_comps, model, alpha=4, group=None):
     """misc.py:1070-1080: weights (1+rmsfactor)/(1+(|sum_band psiH(model)|/rms_comps)^alpha).
     `psiH` is the analysis operator (Psi.dot) at the call site (spotless.py:243-245).
     The band-sum / power / divide run as torch device ops on the (nbasis, Nymax, Nxmax)
-    plane -- executed once per reweighting, not per iteration."""
+    plane -- executed once per reweighting, not per iteration.  group (extension): bands
+    sharded over a torch.distributed group -> the band sum is all-reduced (GPU tensors)."""
     psiH(model, outvar)
+    if group is not None:
+        import torch.distributed as dist
+        plane = torch.sum(outvar, dim=0)
+        dist.all_reduce(plane, op=dist.ReduceOp.SUM, group=None if group is True else group)
+        rc = rms_comps if not _dev.is_numpy(rms_comps) else torch.as_tensor(rms_comps, device=outvar.device)
+        return (1 + rmsfactor) / (1 + torch.abs(plane) ** alpha / rc ** alpha)
     if _dev.is_numpy(outvar):
         mcomps = np.abs(np.sum(outvar, axis=0))
         return (1 + rmsfactor) / (1 + mcomps ** alpha / rms_comps ** alpha)

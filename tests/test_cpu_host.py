@@ -203,3 +203,81 @@ def test_band_sharded_cube_pcg_gloo_world2():
     for rank, err, calls in res:
         assert err < 1e-10, (rank, err)
         assert calls >= 1 + 1 + 3 * 10       # self-test + init + >= 3 reductions per iteration
+
+
+def _pd_worker(rank, world, port, q):
+    """Band-sharded primal-dual backward step, algebra only (oracle operators on CPU): the
+    dual update's band sum becomes local sum -> all-reduce -> apply, exactly the split that
+    pfb_dual_bandsum / pfb_dual_apply make on the GPU (prox/prox_21m.py:_dual_update_sharded),
+    and positivity=2 all-reduces its mask (opt/primal_dual.py).  Checked against the
+    REFERENCE's own trajectories in tests/golden/pd.npz."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pfb_clean_amd.dist import shard_bands
+        from oracle import fftconv as ofc, wavelets as owv
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pd.npz'))
+        psfhat, Q, data = g['psfhat'], int(g['Q']), g['data']
+        nband, P, _ = psfhat.shape
+        nx = ny = P // 2
+        bases = [str(s) for s in g['bases']]
+        nbasis = len(bases)
+        lam, L, nu = float(g['lam']), float(g['hessnorm']), float(nbasis)
+        band0, nb = shard_bands(nband, rank, world)
+        sl = slice(band0, band0 + nb)
+        psi = owv.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+        xpad, xhat, xo = ofc.make_scratch(psfhat[sl], Q, (nb, nx, ny), np.float64)
+        w = np.ones((nbasis, psi.Nymax, psi.Nxmax))
+        sigma = L / 2.0 / nu
+        tau = 0.9 / (L / 2.0 + sigma * nu ** 2)
+        errs = []
+        for tag, pos, maxit in (('pos1_it10', 1, 10), ('pos2_it6', 2, 6)):
+            x = np.zeros((nb, nx, ny))
+            v = np.zeros((nb, nbasis, psi.Nymax, psi.Nxmax))
+            xp, vp = x.copy(), v.copy()
+            xout = np.zeros_like(x)
+            for k in range(maxit):
+                psi.dot(xp, v)
+                vt = vp + sigma * v
+                plane = torch.from_numpy(vt.sum(axis=0))
+                dist.all_reduce(plane)
+                a = np.abs(plane.numpy() / sigma)
+                soft = np.maximum(a - lam * w / sigma, 0.0)
+                fac = np.where(a != 0, 1.0 - soft / np.where(a != 0, a, 1.0), 1.0)
+                v[...] = vt * fac[None]
+                vp = 2 * v - vp
+                psi.hdot(vp, xout)
+                xout += ofc.psf_convolve_cube(xpad, xhat, xo, psfhat[sl], Q, xp) - data[sl]
+                x = xp - tau * xout
+                if pos == 1:
+                    x[x < 0] = 0
+                else:
+                    bad = torch.from_numpy((x <= 0).any(axis=0).astype(np.uint8))
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                    x[:, bad.numpy().astype(bool)] = 0
+                xp[...] = x
+                vp = v.copy()
+            errs.append(float(np.abs(x - g[tag + '_x'][sl]).max() / np.abs(g[tag + '_x']).max()))
+            errs.append(float(np.abs(v - g[tag + '_v'][sl]).max() / np.abs(g[tag + '_v']).max()))
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_sharded_primal_dual_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pd_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, errs in sorted(q.get(timeout=5) for _ in range(2)):
+        assert max(errs) < 1e-9, (rank, errs)
