@@ -581,6 +581,217 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     }
 }
 
+// ------------------------------------------------- row inverse, persistent + pipelined
+// The plain kernel above keeps ONE 1024-thread workgroup per CU (registers), so its phases
+// (strided T loads, FFT, epilogue loads, stores) run strictly one after the other.  This
+// variant keeps the workgroup resident, loops over its row tiles and software-pipelines the
+// strided loads: the 16-byte pieces of the NEXT phase (odd bins of this tile / even bins of
+// the next tile) are requested into registers right after the current phase's pieces were
+// scattered into the LDS and land while that phase's FFT runs.  For this to work no other
+// global load may sit between the request and the FFT's end (s_waitcnt vmcnt retires in
+// order), so w_M^n lives in the LDS as well (w_Q^(2m+1) = w_M^m * w_Q), and the even-bin
+// result is parked in the LDS (not registers) while the odd-bin transform runs.
+template <typename T, int L, int E>
+struct InvP {
+    using C = RowCfg<T, L, true>;
+    using F = RegFft<T, L, E, C::WAVE, 0, true>;
+    static constexpr int G = row_groups<T, L, E, C::GMAX>();
+    static constexpr int NT = G * F::TPB;
+    static constexpr int STRIDE = F::LDS_ELEMS + 4;
+    static constexpr int NVB = FastCfg<T>::NVB;
+    static constexpr int NBE = (L + NVB) / NVB;
+    static constexpr int NBO = L / NVB;
+    static constexpr int BSTEP = NT / G;
+    static constexpr int NITE = (NBE + BSTEP - 1) / BSTEP;
+    static constexpr int NITO = (NBO + BSTEP - 1) / BSTEP;
+    static constexpr int PTWP = (F::PTWC + 1) & ~1;
+    static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (size_t)G * L);
+    static constexpr bool OK = LDS <= (size_t)160 * 1024 && NT == 1024 && !C::WAVE;
+};
+
+template <typename T, int L, int E, int PAR>
+__device__ __forceinline__ void inv_issue(const cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
+                                          Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
+    using P = InvP<T, L, E>;
+    constexpr int NBP = PAR ? P::NBO : P::NBE, NIT = PAR ? P::NITO : P::NITE;
+    const cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * P::NVB;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        int b = bi + k * P::BSTEP;
+        if (b >= NBP) b = NBP - 1;                 // clamped (not skipped): the load count stays static
+        y[k] = loadb<T, P::NVB>(Tp + (size_t)b * nx * P::NVB);
+    }
+}
+
+template <typename T, int L, int E, int PAR>
+__device__ __forceinline__ void inv_scatter(const Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE],
+                                            cplx<T>* yr, int bi) {
+    using P = InvP<T, L, E>;
+    constexpr int NBP = PAR ? P::NBO : P::NBE, NIT = PAR ? P::NITO : P::NITE;
+    // no `if (b < NBP)` here: a conditional use lets the compiler SINK the load into the branch
+    // (load + vmcnt(0) back to back).  Out-of-range threads hold a copy of the last block
+    // (inv_issue clamps the same way) and store the same values to the same place.
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        int b = bi + k * P::BSTEP;
+        if (b >= NBP) b = NBP - 1;
+#pragma unroll
+        for (int h = 0; h < P::NVB; ++h)
+            if (PAR || P::NVB * b + h <= L) yr[P::F::pad(P::NVB * b + h)] = y[k].c[h];
+    }
+}
+
+template <typename T, int L, int E, int PAR>
+__device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm, cplx<T> wq1, int t,
+                                          cplx<T> (&vv)[E]) {
+    using F = typename InvP<T, L, E>::F;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const int m = t + F::TPB * j;
+        cplx<T> yv = lds[F::pad(m)];
+        cplx<T> ym = lds[F::pad(PAR ? (L - 1 - m) : (L - m))];
+        if (!PAR && m == 0) { yv.y = 0; ym.y = 0; }
+        ym = conj(ym);
+        cplx<T> w = ltm[m];
+        if (PAR) w = w * wq1;
+        vv[j] = (yv + ym) + mul_i(mulc(yv - ym, w));
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Values derived from the thread index are loop invariant, so the optimiser computes every
+// LDS / global address of the tile loop once, keeps ~40 of them live across it and spills:
+// scratch reloads are vector-memory operations, and one of them inside an FFT (in-order
+// vmcnt) waits for the prefetch it was supposed to overlap with.  Laundering the index at
+// the top of each iteration makes the (cheap) address arithmetic part of the loop body.
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// MODE 0: no inner products; 1: <x, out>, <out, out>; 2: also <dot_with2, out> (the PCG call)
+template <typename T, int L, int E, int MODE>
+__global__ void __launch_bounds__((InvP<T, L, E>::NT))
+k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
+                const cplx<T>* __restrict__ ptw, const T* __restrict__ x,
+                const T* __restrict__ dot_with2, T* __restrict__ out,
+                double* __restrict__ partials, FastDims d, int band0, int tiles_per_band, int ntiles,
+                T scale, T sigmainv, cplx<T> wq1) {
+    using P = InvP<T, L, E>;
+    using F = typename P::F;
+    constexpr int TPB = F::TPB, G = P::G, NT = P::NT;
+    using V2 = typename vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem + 384);
+    cplx<T>* ltm = ltw + P::PTWP;
+    cplx<T>* lds0 = ltm + L;
+    cplx<T>* park = lds0 + (size_t)G * P::STRIDE;
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptw[k];
+    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    const bool pairing = (G * (int)sizeof(cplx<T>) * P::NVB < 128) && (tiles_per_band & 15) == 0;
+    auto tile = [&](int v, int& bl, int& i0) {
+        bl = v / tiles_per_band;
+        int rg = v - bl * tiles_per_band;
+        if (pairing) {                      // see k_row_inv_pow2: blocks b, b+8 share an XCD's L2
+            const int q = rg >> 4, rem = rg & 15;
+            rg = 2 * (q * 8 + (rem & 7)) + (rem >> 3);
+        }
+        i0 = rg * G;
+    };
+    int bl, i0;
+    tile(vb, bl, i0);
+    Blk<T, P::NVB> y[P::NITE];
+    inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (;;) {
+        const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        int bln, i0n;
+        tile(vbn, bln, i0n);
+        const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
+        cplx<T> vv[E];
+        // ---- even bins
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
+            cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
+            __syncthreads();
+            inv_scatter<T, L, E, 0>(y, lds0 + (size_t)rr * P::STRIDE, bi);
+            inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
+            __syncthreads();
+            inv_build<T, L, E, 0>(lds, ltm, wq1, t, vv);
+            F::template run<true>(vv, lds, t, ltw);
+#pragma unroll
+            for (int j = 0; j < E; ++j) park[j * NT + tid] = vv[j];
+        }
+        // ---- odd bins
+        V2 xq[E], rq[E];
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
+            cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
+            __syncthreads();
+            inv_scatter<T, L, E, 1>(y, lds0 + (size_t)rr * P::STRIDE, bi);
+            const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+            const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+            const V2* dr2 = reinterpret_cast<const V2*>(dot_with2 + rowoff) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                xq[j] = xr[TPB * j];
+                if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
+            }
+            inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, rr, bi, y);
+            __syncthreads();
+            inv_build<T, L, E, 1>(lds, ltm, wq1, t, vv);
+            F::template run<true>(vv, lds, t, ltw);
+        }
+        // ---- z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+            V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> zz = park[j * NT + tid] + mulc(vv[j], ltm[t + TPB * j]);
+                V2 val;
+                const V2 xx = xq[j];
+                val.x = zz.x * scale + sigmainv * xx.x;
+                val.y = zz.y * scale + sigmainv * xx.y;
+                orow[TPB * j] = val;
+                if constexpr (MODE >= 1) {
+                    acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
+                    if constexpr (MODE == 2) {
+                        const V2 d2 = rq[j];
+                        acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
+                    }
+                    acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
+                }
+            }
+        }
+        if (vbn == vb) break;
+        vb = vbn; bl = bln; i0 = i0n;
+    }
+    if constexpr (MODE >= 1) {
+        __syncthreads();
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            // one slot per tile (k_sum_partials adds them all): the total goes to this
+            // workgroup's first tile, zeros to its others
+            const size_t np = (size_t)ntiles;
+            bool first = true;
+            for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
+                partials[v] = first ? acc[0] : 0.0;
+                partials[np + v] = first ? acc[1] : 0.0;
+                partials[2 * np + v] = first ? acc[2] : 0.0;
+                first = false;
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------- host side
 struct FastTables {            // device tables owned by the plan (stored behind p->fast_tables)
     void* ptw_col;
@@ -589,6 +800,7 @@ struct FastTables {            // device tables owned by the plan (stored behind
     void* ptw_row_inv;         // inverse row kernel (E = 8): COMPACT table, copied to LDS
     void* twM;                 // exp(-2 pi i n / M), n < L
     int col_persistent;        // PFB_COL_PERSIST (default: auto by size): persistent prefetching column kernel
+    int inv_persistent;        // PFB_INV_PERSIST (default 1): persistent pipelined inverse row kernel where it fits
     int num_cu;
 };
 
@@ -612,6 +824,20 @@ static int prep_ptw_compact(void** dev) {
     if (n > 0) fill_ptw_compact<T, N, E>(h.data());
     PFB_HIP_CHECK(hipMalloc(dev, sizeof(cplx<T>) * h.size()));
     PFB_HIP_CHECK(hipMemcpy(*dev, h.data(), sizeof(cplx<T>) * h.size(), hipMemcpyHostToDevice));
+    return PFB_OK;
+}
+
+template <typename T, int L>
+static int set_invp_attr() {
+    constexpr int E = RowCfg<T, L, true>::E;
+    if constexpr (InvP<T, L, E>::OK) {
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 0>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 1>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 2>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
     return PFB_OK;
 }
 
@@ -642,7 +868,8 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2<T, NN, RowCfg<T, NN, false>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, RowCfg<T, NN, true>::E>, \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
+        if (rc == PFB_OK) rc = set_invp_attr<T, NN>(); break;
         PFB_POW2_SIZES(X)
 #undef X
         default: break;
@@ -697,6 +924,8 @@ int pow2_prepare(pfb_conv_plan* p) {
     // 2048^2 x 8), the plain 2-workgroup/CU kernel at 4096 (1.17 vs 1.22 ms); 0 / 1 force one
     ft->col_persistent = -1;
     if (const char* e = getenv("PFB_COL_PERSIST")) ft->col_persistent = atoi(e) ? 1 : 0;
+    ft->inv_persistent = 1;
+    if (const char* e = getenv("PFB_INV_PERSIST")) ft->inv_persistent = atoi(e) ? 1 : 0;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -780,6 +1009,28 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
+    if constexpr (InvP<T, L, E>::OK) {
+        // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
+        const bool plain_dots = !dot_with || (dot_with == x);
+        if (ft->inv_persistent && !beam && plain_dots && !(dot_with2 && !dot_with)) {
+            using IP = InvP<T, L, E>;
+            const int tiles_per_band = p->nx / G, ntiles = tiles_per_band * nb;
+            const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
+            const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
+            const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
+#define PFB_INVP(MODE)                                                                                  \
+            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
+                               (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
+                               (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)dot_with2,       \
+                               (T*)out, p->partials, d, band0, tiles_per_band, ntiles, (T)scale,        \
+                               (T)sigmainv, wq1)
+            if (!dot_with) PFB_INVP(0);
+            else if (!dot_with2) PFB_INVP(1);
+            else PFB_INVP(2);
+#undef PFB_INVP
+            return;
+        }
+    }
     const size_t lds = 384 + sizeof(cplx<T>) * ((size_t)((F::PTWC + 1) & ~1) + (size_t)G * (F::LDS_ELEMS + 4) * (InvDb<T, L>::ON ? 2 : 1));
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,

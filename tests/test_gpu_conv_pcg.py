@@ -138,6 +138,43 @@ def test_conv_tensor_path_and_fused_dot(amd, shape):
     assert relerr(out1[0].cpu().numpy(), ref1) < 1e-12
 
 
+@pmp('mode', [0, 1, 2])
+def test_persistent_row_inverse_multi_tile(amd, mode):
+    """ny = 4096 fp32 takes the persistent pipelined inverse row kernel (k_row_inv_pow2p); with
+    3 bands x 1024 rows every workgroup walks several row tiles and crosses band boundaries.
+    mode 0: no inner products, 1: <x, out>, <out, out>, 2: + <w, out> (pfb_psfconv_apply_dots,
+    the call the fused PCG makes)."""
+    from pfb_clean_amd import _lib, _dev
+    rng = np.random.default_rng(21)
+    nb, nx, ny = 3, 1024, 4096
+    P, Q = 2 * nx, 2 * ny
+    psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
+    x = rng.standard_normal((nb, nx, ny)).astype(np.float32)
+    w = rng.standard_normal((nb, nx, ny)).astype(np.float32)
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref = ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, x.astype(np.float64), sigmainv=0.3, wsum=1.7)
+    dev = torch.device('cuda')
+    plan = amd.psf.PsfConvPlan(torch.from_numpy(psfhat.astype(np.complex64)).to(dev), nx, ny, Q)
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    out = torch.empty_like(xt)
+    dots = torch.zeros(3, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    if mode == 0:
+        plan.apply(xt, out=out, wsum=1.7, sigmainv=0.3)
+    else:
+        _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(xt), None, 1.7, 0.3, _dev.ptr(out),
+                                              _dev.ptr(xt), _dev.ptr(wt) if mode == 2 else None,
+                                              _dev.ptr(dots), _dev.stream()))
+    o = out.cpu().numpy().astype(np.float64)
+    assert relerr(o, ref) < TOL_CONV[np.float32]
+    if mode:
+        d = dots.cpu().numpy()
+        assert abs(d[0] - np.vdot(x.astype(np.float64), o)) < 1e-9 * np.vdot(o, o) ** 0.5 * np.linalg.norm(x)
+        assert abs(d[2] - np.vdot(o, o)) < 1e-9 * np.vdot(o, o)
+        if mode == 2:
+            assert abs(d[1] - np.vdot(w.astype(np.float64), o)) < 1e-9 * np.vdot(o, o) ** 0.5 * np.linalg.norm(w)
+
+
 @pmp('rdt', [np.float64, np.float32])
 def test_fast_path_equals_generic_path(amd, rdt, monkeypatch):
     """Same plan sizes through both kernel families (PFB_FORCE_GENERIC picks the coverage
