@@ -42,6 +42,27 @@ struct alignas(2 * sizeof(T)) cplx {
     __host__ __device__ cplx(T a, T b) : x(a), y(b) {}
 };
 
+// complex64 lives in an aligned VGPR pair and computes with the PACKED fp32 instructions of
+// CDNA3/4 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two lanes of a 64-bit operand per
+// issue, with per-lane source selection op_sel / op_sel_hi and per-lane negation neg_lo /
+// neg_hi).  A complex add is ONE VALU instruction, a complex multiply TWO (instead of 2 / 4):
+// the FFT kernels are VALU-issue bound (rocprofv3 SQ_INSTS_VALU x 4 cycles = 55-65 % of the
+// kernel time before this), so instruction count is time.  clang does emit v_pk_* for
+// ext_vector arithmetic but cannot fold the swizzles and half-negations of complex
+// arithmetic into the modifiers (it adds v_xor / v_mov), hence the asm bodies below; its SLP
+// vectoriser on scalar code was worse still (see the Makefile).
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <>
+struct alignas(8) cplx<float> {
+    union {
+        struct { float x, y; };
+        v2f v;
+    };
+    __host__ __device__ cplx() = default;
+    __host__ __device__ cplx(float a, float b) : x(a), y(b) {}
+    __host__ __device__ explicit cplx(v2f q) : v(q) {}
+};
+
 template <typename T> __device__ __forceinline__ cplx<T> operator+(cplx<T> a, cplx<T> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename T> __device__ __forceinline__ cplx<T> operator-(cplx<T> a, cplx<T> b) { return {a.x - b.x, a.y - b.y}; }
 template <typename T> __device__ __forceinline__ cplx<T> operator*(cplx<T> a, cplx<T> b) {
@@ -56,6 +77,64 @@ template <typename T> __device__ __forceinline__ cplx<T> mulc(cplx<T> a, cplx<T>
 // multiply by +i / -i
 template <typename T> __device__ __forceinline__ cplx<T> mul_i(cplx<T> a)  { return {-a.y, a.x}; }
 template <typename T> __device__ __forceinline__ cplx<T> mul_mi(cplx<T> a) { return {a.y, -a.x}; }
+
+// a + rot(b), rot = multiplication by -i (INV = false) / +i (INV = true); a +- conj(b)
+template <bool INV, typename T> __device__ __forceinline__ cplx<T> addrot(cplx<T> a, cplx<T> b) {
+    return INV ? cplx<T>(a.x - b.y, a.y + b.x) : cplx<T>(a.x + b.y, a.y - b.x);
+}
+template <typename T> __device__ __forceinline__ cplx<T> addc(cplx<T> a, cplx<T> b) { return {a.x + b.x, a.y - b.y}; }
+template <typename T> __device__ __forceinline__ cplx<T> subc(cplx<T> a, cplx<T> b) { return {a.x - b.x, a.y + b.y}; }
+
+// ---- complex64: packed overloads (non-template: preferred over the generic ones above)
+using cf32 = cplx<float>;
+__device__ __forceinline__ cf32 operator+(cf32 a, cf32 b) { return cf32(a.v + b.v); }
+__device__ __forceinline__ cf32 operator-(cf32 a, cf32 b) { return cf32(a.v - b.v); }
+__device__ __forceinline__ cf32 operator*(float s, cf32 a) { return cf32(a.v * s); }
+__device__ __forceinline__ cf32 operator*(cf32 a, cf32 b) {
+    v2f t, r;       // t = (ax bx, ay bx);  r = (-ay by + t.lo, ax by + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a.v), "v"(b.v));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a.v), "v"(b.v), "v"(t));
+    return cf32(r);
+}
+__device__ __forceinline__ cf32 mulc(cf32 a, cf32 b) {       // a * conj(b)
+    v2f t, r;       // t = (ax bx, ay bx);  r = (ay by + t.lo, -ax by + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a.v), "v"(b.v));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(a.v), "v"(b.v), "v"(t));
+    return cf32(r);
+}
+template <bool INV> __device__ __forceinline__ cf32 addrot(cf32 a, cf32 b) {
+    v2f r;          // INV: (ax - by, ay + bx)   else: (ax + by, ay - bx)
+    if constexpr (INV)
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    else
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    return cf32(r);
+}
+__device__ __forceinline__ cf32 addc(cf32 a, cf32 b) {       // a + conj(b)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    return cf32(r);
+}
+__device__ __forceinline__ cf32 subc(cf32 a, cf32 b) {       // a - conj(b)
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    return cf32(r);
+}
+// (x, y) -> (x + y, y - x) = a (1 - i)   and   (x - y, x + y) = a (1 + i): the w_8 rotations
+__device__ __forceinline__ cf32 mul_1mi(cf32 a) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a.v));
+    return cf32(r);
+}
+__device__ __forceinline__ cf32 mul_1pi(cf32 a) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a.v));
+    return cf32(r);
+}
+template <typename T> __device__ __forceinline__ cplx<T> mul_1mi(cplx<T> a) { return {a.x + a.y, a.y - a.x}; }
+template <typename T> __device__ __forceinline__ cplx<T> mul_1pi(cplx<T> a) { return {a.x - a.y, a.x + a.y}; }
 
 // ------------------------------------------------------------------ reductions
 // wave64 shuffle reduction, then LDS across waves.  Result valid in thread 0.

@@ -81,7 +81,14 @@ void fill_ptw_compact(cplx<T>* out) {
 // ------------------------------------------------------------- small in-register DFTs
 template <typename T, bool INV>
 __device__ __forceinline__ cplx<T> rot90(cplx<T> a) {   // multiply by -i (fwd) / +i (inv)
-    return INV ? cplx<T>(-a.y, a.x) : cplx<T>(a.y, -a.x);
+    if constexpr (sizeof(T) == 4) {
+        v2f r;          // one packed add with 0: swizzle + half negation in the modifiers
+        if constexpr (INV) asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a.v));
+        else               asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a.v));
+        return cplx<T>(r);
+    } else {
+        return INV ? cplx<T>(-a.y, a.x) : cplx<T>(a.y, -a.x);
+    }
 }
 
 template <typename T, bool INV>
@@ -93,11 +100,11 @@ __device__ __forceinline__ void dft2(cplx<T>& a, cplx<T>& b) {
 
 template <typename T, bool INV>
 __device__ __forceinline__ void dft4(cplx<T>& a0, cplx<T>& a1, cplx<T>& a2, cplx<T>& a3) {
-    cplx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<T, INV>(a1 - a3);
+    const cplx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
-    a1 = t1 + t3;
+    a1 = addrot<INV>(t1, d);         // t1 + rot(d)   (one packed add with swizzle for fp32)
     a2 = t0 - t2;
-    a3 = t1 - t3;
+    a3 = addrot<!INV>(t1, d);        // t1 - rot(d)
 }
 
 // multiply by exp(-+ 2 pi i m / 16) with compile-time m
@@ -111,16 +118,18 @@ __device__ __forceinline__ cplx<T> mul_w16(cplx<T> a) {
     else if constexpr (mm == 4) return rot90<T, INV>(a);
     else if constexpr (mm == 8) return cplx<T>(-a.x, -a.y);
     else if constexpr (mm == 12) return rot90<T, !INV>(a);
+    else if constexpr (mm == 2)  return h * (INV ? mul_1pi(a) : mul_1mi(a));
+    else if constexpr (mm == 14) return h * (INV ? mul_1mi(a) : mul_1pi(a));
+    else if constexpr (mm == 6)  return (-h) * (INV ? mul_1mi(a) : mul_1pi(a));
+    else if constexpr (mm == 10) return (-h) * (INV ? mul_1pi(a) : mul_1mi(a));
     else {
         // w = (wr, -wi) forward, (wr, +wi) inverse
-        constexpr T wr = (mm == 1) ? c : (mm == 2) ? h : (mm == 3) ? s : (mm == 5) ? -s : (mm == 6) ? -h
-                       : (mm == 7) ? -c : (mm == 9) ? -c : (mm == 10) ? -h : (mm == 11) ? -s
-                       : (mm == 13) ? s : (mm == 14) ? h : c;
-        constexpr T wi = (mm == 1) ? s : (mm == 2) ? h : (mm == 3) ? c : (mm == 5) ? c : (mm == 6) ? h
-                       : (mm == 7) ? s : (mm == 9) ? -s : (mm == 10) ? -h : (mm == 11) ? -c
-                       : (mm == 13) ? -c : (mm == 14) ? -h : -s;
+        constexpr T wr = (mm == 1) ? c : (mm == 3) ? s : (mm == 5) ? -s : (mm == 7) ? -c : (mm == 9) ? -c
+                       : (mm == 11) ? -s : (mm == 13) ? s : c;
+        constexpr T wi = (mm == 1) ? s : (mm == 3) ? c : (mm == 5) ? c : (mm == 7) ? s : (mm == 9) ? -s
+                       : (mm == 11) ? -c : (mm == 13) ? -c : -s;
         const T wy = INV ? wi : -wi;
-        return cplx<T>(a.x * wr - a.y * wy, a.x * wy + a.y * wr);
+        return a * cplx<T>(wr, wy);
     }
 }
 
@@ -138,15 +147,19 @@ template <typename T, bool INV> struct Dft<T, INV, 8> {
         dft4<T, INV>(u[0], u[2], u[4], u[6]);
         dft4<T, INV>(u[1], u[3], u[5], u[7]);
         u[3] = mul_w16<T, INV, 2>(u[3]);
-        u[5] = mul_w16<T, INV, 4>(u[5]);
         u[7] = mul_w16<T, INV, 6>(u[7]);
-        // now b[nl][k1] sits in u[nl + 2 k1]
+        // now b[nl][k1] sits in u[nl + 2 k1]; the w8^2 = -+i rotation of u[5] rides on the adds
         cplx<T> x[8];
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) {
-            cplx<T> p = u[2 * k1], q = u[2 * k1 + 1];
-            x[k1] = p + q;
-            x[k1 + 4] = p - q;
+            const cplx<T> p = u[2 * k1], q = u[2 * k1 + 1];
+            if (k1 == 2) {
+                x[k1] = addrot<INV>(p, q);
+                x[k1 + 4] = addrot<!INV>(p, q);
+            } else {
+                x[k1] = p + q;
+                x[k1 + 4] = p - q;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) u[k] = x[k];
@@ -237,33 +250,29 @@ struct RegFft {
                     if constexpr (R > 4) w4 = tb[2 * P];
                     if constexpr (R > 8) w8 = tb[3 * P];
                 }
-                if constexpr (INV) {
-                    w1.y = -w1.y;
-                    if constexpr (R > 2) w2.y = -w2.y;
-                    if constexpr (R > 4) w4.y = -w4.y;
-                    if constexpr (R > 8) w8.y = -w8.y;
-                }
-                u[1] = u[1] * w1;
+                // inverse transform: multiply by the conjugates (mulc), no sign flips on w
+                auto tw = [](cplx<T> a, cplx<T> w) { return INV ? mulc(a, w) : a * w; };
+                u[1] = tw(u[1], w1);
                 if constexpr (R > 2) {
-                    u[2] = u[2] * w2;
+                    u[2] = tw(u[2], w2);
                     const cplx<T> w3 = w1 * w2;
-                    u[3] = u[3] * w3;
+                    u[3] = tw(u[3], w3);
                     if constexpr (R > 4) {
-                        u[4] = u[4] * w4;
+                        u[4] = tw(u[4], w4);
                         const cplx<T> w7 = w3 * w4;
-                        u[7] = u[7] * w7;
-                        if constexpr (R > 8) { u[11] = u[11] * (w3 * w8); u[15] = u[15] * (w7 * w8); }
+                        u[7] = tw(u[7], w7);
+                        if constexpr (R > 8) { u[11] = tw(u[11], w3 * w8); u[15] = tw(u[15], w7 * w8); }
                         const cplx<T> w5 = w1 * w4;
-                        u[5] = u[5] * w5;
-                        if constexpr (R > 8) u[13] = u[13] * (w5 * w8);
+                        u[5] = tw(u[5], w5);
+                        if constexpr (R > 8) u[13] = tw(u[13], w5 * w8);
                         const cplx<T> w6 = w2 * w4;
-                        u[6] = u[6] * w6;
+                        u[6] = tw(u[6], w6);
                         if constexpr (R > 8) {
-                            u[14] = u[14] * (w6 * w8);
-                            u[8] = u[8] * w8;
-                            u[9] = u[9] * (w1 * w8);
-                            u[10] = u[10] * (w2 * w8);
-                            u[12] = u[12] * (w4 * w8);
+                            u[14] = tw(u[14], w6 * w8);
+                            u[8] = tw(u[8], w8);
+                            u[9] = tw(u[9], w1 * w8);
+                            u[10] = tw(u[10], w2 * w8);
+                            u[12] = tw(u[12], w4 * w8);
                         }
                     }
                 }

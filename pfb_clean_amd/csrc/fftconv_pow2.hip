@@ -379,8 +379,8 @@ __device__ __forceinline__ void row_fwd_post(const cplx<T> (&z)[E], const cplx<T
             const int ib = PAR ? (L - 1 - m) : ((m == 0 || m > L) ? 0 : L - m);
             const cplx<T> w = twQ[valid ? 2 * m + PAR : 0];
             const cplx<T> zv = zr[F::pad(ia)];
-            const cplx<T> zm = conj(zr[F::pad(ib)]);
-            o.c[h] = T(0.5) * ((zv + zm) + mul_mi(w * (zv - zm)));
+            const cplx<T> zm = zr[F::pad(ib)];
+            o.c[h] = T(0.5) * addrot<false>(addc(zv, zm), w * subc(zv, zm));
             if (!valid) o.c[h] = cplx<T>(0, 0);
         }
         storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
@@ -482,9 +482,8 @@ __device__ __forceinline__ void row_inv_phase(PF&& after_loads_issued, const cpl
         cplx<T> yv = lds[F::pad(m)];
         cplx<T> ym = lds[F::pad(PAR ? (L - 1 - m) : (L - m))];
         if (!PAR && m == 0) { yv.y = 0; ym.y = 0; }
-        ym = conj(ym);
         const cplx<T> w = twQ[2 * m + PAR];
-        vv[j] = (yv + ym) + mul_i(mulc(yv - ym, w));
+        vv[j] = addrot<true>(addc(yv, ym), mulc(subc(yv, ym), w));
         // bound the number of LDS / twiddle loads in flight (else all 3 E are hoisted: spills)
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -651,10 +650,9 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
         cplx<T> yv = lds[F::pad(m)];
         cplx<T> ym = lds[F::pad(PAR ? (L - 1 - m) : (L - m))];
         if (!PAR && m == 0) { yv.y = 0; ym.y = 0; }
-        ym = conj(ym);
         cplx<T> w = ltm[m];
         if (PAR) w = w * wq1;
-        vv[j] = (yv + ym) + mul_i(mulc(yv - ym, w));
+        vv[j] = addrot<true>(addc(yv, ym), mulc(subc(yv, ym), w));
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -969,7 +967,12 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
     constexpr int GC = col_groups<H, E>();
     const int nblk = fast_nblocks(p->ny / 2, FastCfg<T>::NVB);
     const size_t lds = sizeof(cplx<T>) * (size_t)GC * FastCfg<T>::NVB * F::LDS_ELEMS;
-    if (ft->col_persistent == 1 || (ft->col_persistent < 0 && H <= 2048)) {
+    // persistent kernel: needs its LDS (exchange buffers + twiddle table) to fit; measured faster
+    // for H >= 2048 (fp32, packed arithmetic: 1.07 vs 1.32 ms at 4096^2 x 8, 0.276 vs 0.347 at 2048^2 x 8;
+    // fp64: 1.19 vs 1.41 and 0.266 vs 0.333 at x 4; a tie or a small loss at H <= 1024)
+    const size_t lds_p = lds + sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1);
+    const bool fits_p = lds_p <= (size_t)160 * 1024;
+    if (fits_p && (ft->col_persistent == 1 || (ft->col_persistent < 0 && H >= 2048))) {
         // one resident workgroup set: 8 waves per CU at 256 VGPRs
         const int nitems = nblk * nb;
         const int wg_per_cu = (8 * 64) / (GC * F::TPB) > 0 ? (8 * 64) / (GC * F::TPB) : 1;
