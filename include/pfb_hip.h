@@ -105,10 +105,11 @@ int pfb_psfconv_apply_dots(pfb_conv_plan* plan, int band0, int nb,
 int    pfb_psfconv_plan_info(const pfb_conv_plan* plan, int* fast_path, int* vb,
                              size_t* workspace_bytes);
 
-/* Per-stage timing for benchmarks: while on, every apply records HIP events on its
- * stream around the three kernels (row-forward, column, row-inverse); get_profile
- * waits for them, returns the summed milliseconds per stage and the number of applies
- * covered (at most 512 between calls), and resets the counters. */
+/* Per-stage timing for benchmarks: while on > 0, every on-th apply (on = 1: every apply)
+ * records HIP events on its stream around the three kernels (row-forward, column,
+ * row-inverse) -- an event record costs ~6 us of stream time, hence the sampling period;
+ * get_profile waits for them, returns the summed milliseconds per stage and the number of
+ * applies covered (at most 512 between calls), and resets the counters. */
 int pfb_psfconv_set_profiling(pfb_conv_plan* plan, int on);
 int pfb_psfconv_get_profile(pfb_conv_plan* plan, double stage_ms[3], int* napply);
 

@@ -32,9 +32,10 @@ struct pfb_conv_plan {
     size_t workspace_bytes;
     int have_psf;
     int partials_per_band;     // fused-dot partial sums emitted per band by row_inv
+    int last_npartials;        // slots per quantity the LAST row-inverse launch wrote (k_sum_partials reads these)
     void* fast_tables;         // pow2 path: per-pass twiddle tables (fftconv_pow2.hip)
     // optional per-stage timing (bench.py roofline): 4 events per apply, up to PROF_MAX applies
-    int prof_on, prof_n;
+    int prof_on, prof_n, prof_tick;   // prof_on = sampling period (every prof_on-th apply is timed)
     hipEvent_t* prof_ev;
 };
 
@@ -42,8 +43,12 @@ namespace pfb {
 constexpr int PROF_MAX = 512;
 // record stage boundary `k` (0..3) of the current apply on `st` when profiling is on
 inline void prof_mark(pfb_conv_plan* p, hipStream_t st, int k) {
-    if (!p->prof_on || p->prof_n >= PROF_MAX) return;
-    (void)hipEventRecord(p->prof_ev[p->prof_n * 4 + k], st);
-    if (k == 3) p->prof_n++;
+    if (!p->prof_on) return;
+    const bool sampled = (p->prof_tick % p->prof_on) == 0 && p->prof_n < PROF_MAX;
+    if (sampled) (void)hipEventRecord(p->prof_ev[p->prof_n * 4 + k], st);
+    if (k == 3) {
+        if (sampled) p->prof_n++;
+        p->prof_tick++;
+    }
 }
 }  // namespace pfb

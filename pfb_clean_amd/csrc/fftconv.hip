@@ -353,8 +353,9 @@ int pfb_psfconv_set_profiling(pfb_conv_plan* p, int on) {
         PFB_REQUIRE(p->prof_ev != nullptr, PFB_ERR_ALLOC, "set_profiling: host alloc failed");
         for (int k = 0; k < 4 * PROF_MAX; ++k) PFB_HIP_CHECK(hipEventCreate(&p->prof_ev[k]));
     }
-    p->prof_on = on ? 1 : 0;
+    p->prof_on = on > 0 ? on : 0;
     p->prof_n = 0;
+    p->prof_tick = 0;
     return PFB_OK;
 }
 
@@ -408,6 +409,7 @@ static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, cons
     double scale = 1.0 / ((double)p->P * (double)p->Q);
     if (wsum > 0) scale /= wsum;
     int rc;
+    p->last_npartials = p->partials_per_band * nb;        // the persistent row-inverse kernel lowers it
     if (p->fast)
         rc = pow2_apply(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     else if (p->dtype == PFB_F32)
@@ -417,7 +419,7 @@ static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, cons
     if (rc != PFB_OK) return rc;
     if (dot_with) {
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials,
-                           p->partials_per_band * nb, ndots, dots_out);
+                           p->last_npartials, ndots, dots_out);
         PFB_HIP_CHECK(hipGetLastError());
     }
     return PFB_OK;

@@ -775,17 +775,11 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     if constexpr (MODE >= 1) {
         __syncthreads();
         block_sum<3>(acc, red);
-        if (threadIdx.x == 0) {
-            // one slot per tile (k_sum_partials adds them all): the total goes to this
-            // workgroup's first tile, zeros to its others
-            const size_t np = (size_t)ntiles;
-            bool first = true;
-            for (int v = blockIdx.x; v < ntiles; v += gridDim.x) {
-                partials[v] = first ? acc[0] : 0.0;
-                partials[np + v] = first ? acc[1] : 0.0;
-                partials[2 * np + v] = first ? acc[2] : 0.0;
-                first = false;
-            }
+        if (threadIdx.x == 0) {           // one slot per WORKGROUP (launcher: last_npartials = grid)
+            const size_t np = gridDim.x;
+            partials[blockIdx.x] = acc[0];
+            partials[np + blockIdx.x] = acc[1];
+            partials[2 * np + blockIdx.x] = acc[2];
         }
     }
 }
@@ -1027,6 +1021,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
                                (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)dot_with2,       \
                                (T*)out, p->partials, d, band0, tiles_per_band, ntiles, (T)scale,        \
                                (T)sigmainv, wq1)
+            p->last_npartials = grid;
             if (!dot_with) PFB_INVP(0);
             else if (!dot_with2) PFB_INVP(1);
             else PFB_INVP(2);

@@ -93,7 +93,9 @@ class PsfConvPlan:
         return out3[0] if squeeze else out3
 
     def set_profiling(self, on):
-        _lib.check(self._lib.pfb_psfconv_set_profiling(self._h, int(bool(on))))
+        """on: False/0 off, True/1 every apply, N > 1 every N-th apply (each timed apply puts
+        four event records = ~20 us on the stream)."""
+        _lib.check(self._lib.pfb_psfconv_set_profiling(self._h, int(on)))
 
     def get_profile(self):
         """(ms_row_fwd, ms_col, ms_row_inv) summed over `napply` applies, napply."""
