@@ -215,7 +215,8 @@ struct RegFft {
         else __syncthreads();
     }
     static constexpr int TPB = N / E;
-    static constexpr int LDS_ELEMS = N + N / 16;
+    static constexpr int RM = rmax_of(E);
+    static constexpr int LDS_ELEMS = N + N / (RM < 16 ? RM : 16);   // room for every padding below
     static constexpr int PTW = ptw_total<N, E>();
     static constexpr int PTWC = ptw_total<N, E>() / 4;          // compact (w only) table size
 
@@ -224,6 +225,27 @@ struct RegFft {
     // every (base, constant) pair used below; it lets the 16 LDS accesses of a thread
     // share ONE address register with compile-time immediates.
     static constexpr int cpad(int c) { return c + (c >> 4); }
+
+    // Padding of the EXCHANGE after the pass with predecessor product P (radix R), chosen per
+    // pass so that the scattered writes are bank-conflict free (the reads are contiguous):
+    //   P = 1   lane i writes element i*R (+s): stride-R -> one extra element per 256 bytes
+    //           of lanes (fp32: c + c/32, fp64: c + c/16)
+    //   P > 1   P consecutive lanes write P contiguous elements, the next P lanes start P*R
+    //           further: shift every P*R block by P elements; nothing needed once P lanes
+    //           alone cover the 64 banks (P >= 32 fp32 / 16 fp64).
+    // (the uniform i + i/16 gave 2-way conflicts on the P = 1 and P = 8 writes: ~35 % of all
+    // LDS cycles of the column kernel, SQ_LDS_BANK_CONFLICT / SQ_LDS_ACTIVE)
+    // As for pad/cpad above: xpad(b + c) == xpad(b) + cxpad(c) for every (base, constant) used.
+    static constexpr int CB = (int)sizeof(cplx<T>);
+    static constexpr int WLANES = 256 / CB;
+    template <int P, int R>
+    static constexpr int cxpad(int c) {
+        if (P == 1) return c + (c >> (CB == 8 ? 5 : 4));
+        if (P >= WLANES) return c;
+        return c + (c / (P * R)) * P;
+    }
+    template <int P, int R>
+    __device__ __forceinline__ static int xpad(int c) { return cxpad<P, R>(c); }
 
     // twiddle + butterflies of the pass whose predecessor product is P
     template <bool INV, int P>
@@ -303,14 +325,14 @@ struct RegFft {
                     for (int q = 0; q < NB; ++q) {
                         const int i = t + TPB * q;
                         const int k = i & (P - 1);
-                        cplx<T>* wp = lds + pad((i - k) * R + k);
+                        cplx<T>* wp = lds + xpad<P, R>((i - k) * R + k);
 #pragma unroll
-                        for (int s = 0; s < R; ++s) wp[cpad(s * P)] = v[n][q + s * NB];
+                        for (int s = 0; s < R; ++s) wp[cxpad<P, R>(s * P)] = v[n][q + s * NB];
                     }
                     sync();
-                    const cplx<T>* rp = lds + pad(t);
+                    const cplx<T>* rp = lds + xpad<P, R>(t);
 #pragma unroll
-                    for (int j = 0; j < E; ++j) v[n][j] = rp[cpad(TPB * j)];
+                    for (int j = 0; j < E; ++j) v[n][j] = rp[cxpad<P, R>(TPB * j)];
                 }
             } else {
             if constexpr (DBOFF == 0) sync();      // previous readers of `lds` are done
@@ -318,19 +340,19 @@ struct RegFft {
             for (int q = 0; q < NB; ++q) {
                 const int i = t + TPB * q;
                 const int k = i & (P - 1);
-                cplx<T>* wp = lds + pad((i - k) * R + k);
+                cplx<T>* wp = lds + xpad<P, R>((i - k) * R + k);
 #pragma unroll
                 for (int n = 0; n < NV; ++n) {
 #pragma unroll
-                    for (int s = 0; s < R; ++s) wp[n * LDS_ELEMS + cpad(s * P)] = v[n][q + s * NB];
+                    for (int s = 0; s < R; ++s) wp[n * LDS_ELEMS + cxpad<P, R>(s * P)] = v[n][q + s * NB];
                 }
             }
             sync();
-            const cplx<T>* rp = lds + pad(t);
+            const cplx<T>* rp = lds + xpad<P, R>(t);
 #pragma unroll
             for (int n = 0; n < NV; ++n) {
 #pragma unroll
-                for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cpad(TPB * j)];
+                for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cxpad<P, R>(TPB * j)];
             }
             }
             pass<INV, P * R, NV, XCH + 1>(v, lds_in, t, ptw);

@@ -66,7 +66,7 @@ template <typename T, int L, bool INVK> struct RowCfg {
 template <typename T, int L> struct InvDb {
     using C = RowCfg<T, L, true>;
     static constexpr int G = row_groups<T, L, C::E, C::GMAX>();
-    static constexpr int STRIDE = L + L / 16 + 4;
+    static constexpr int STRIDE = RegFft<T, L, C::E>::LDS_ELEMS + 4;
     static constexpr bool ON = (size_t)(2 * G * STRIDE + L) * sizeof(cplx<T>) + 384 <= (size_t)152 * 1024;
     static constexpr int OFF = ON ? G * STRIDE : 0;
 };
@@ -78,7 +78,7 @@ template <typename T, int L, int E, int GMAX>
 constexpr int row_groups() {
     constexpr int TPB = L / E;
     int G = 256 / TPB > GMAX ? 256 / TPB : GMAX;
-    const int stride = (L + L / 16 + 4);
+    const int stride = RegFft<T, L, E>::LDS_ELEMS + 4;
     while (G > 2 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 384 > LDS_BUDGET)) G /= 2;
     return G;
 }
