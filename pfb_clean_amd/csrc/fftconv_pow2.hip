@@ -594,7 +594,8 @@ template <typename T, int L, int E>
 struct InvP {
     using C = RowCfg<T, L, true>;
     using F = RegFft<T, L, E, C::WAVE, 0, true>;
-    static constexpr int G = row_groups<T, L, E, C::GMAX>();
+    // always a full 1024-thread workgroup: 4 rows at L = 2048, 8 rows (128-byte pieces) at L = 1024
+    static constexpr int G = 1024 / F::TPB;
     static constexpr int NT = G * F::TPB;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
@@ -605,7 +606,7 @@ struct InvP {
     static constexpr int NITO = (NBO + BSTEP - 1) / BSTEP;
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (size_t)G * L);
-    static constexpr bool OK = LDS <= (size_t)160 * 1024 && NT == 1024 && !C::WAVE;
+    static constexpr bool OK = LDS <= (size_t)160 * 1024 && NT == 1024 && G >= 4 && G <= 16 && !C::WAVE;
 };
 
 template <typename T, int L, int E, int PAR>
@@ -1011,7 +1012,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
         const bool plain_dots = !dot_with || (dot_with == x);
         if (ft->inv_persistent && !beam && plain_dots && !(dot_with2 && !dot_with)) {
             using IP = InvP<T, L, E>;
-            const int tiles_per_band = p->nx / G, ntiles = tiles_per_band * nb;
+            const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));

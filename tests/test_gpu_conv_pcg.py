@@ -87,6 +87,8 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
     # power-of-two with 2x oversampling: the register-resident fast path
     (64, 128, 128, 256), (128, 256, 256, 512), (512, 128, 1024, 256), (1024, 1024, 2048, 2048),
     (2048, 256, 4096, 512), (256, 4096, 512, 8192), (4096, 128, 8192, 256),
+    # the largest instantiations (BASELINE config #5 is 8192 x 8192)
+    (8192, 128, 16384, 256), (64, 8192, 128, 16384), (128, 2048, 256, 4096),
 ]
 
 
@@ -138,15 +140,16 @@ def test_conv_tensor_path_and_fused_dot(amd, shape):
     assert relerr(out1[0].cpu().numpy(), ref1) < 1e-12
 
 
+@pmp('ny', [4096, 2048])
 @pmp('mode', [0, 1, 2])
-def test_persistent_row_inverse_multi_tile(amd, mode):
+def test_persistent_row_inverse_multi_tile(amd, mode, ny):
     """ny = 4096 fp32 takes the persistent pipelined inverse row kernel (k_row_inv_pow2p); with
     3 bands x 1024 rows every workgroup walks several row tiles and crosses band boundaries.
     mode 0: no inner products, 1: <x, out>, <out, out>, 2: + <w, out> (pfb_psfconv_apply_dots,
     the call the fused PCG makes)."""
     from pfb_clean_amd import _lib, _dev
     rng = np.random.default_rng(21)
-    nb, nx, ny = 3, 1024, 4096
+    nb, nx = 3, (1024 if ny == 4096 else 4096)      # 768 / 1536 row tiles on 256 workgroups
     P, Q = 2 * nx, 2 * ny
     psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
     x = rng.standard_normal((nb, nx, ny)).astype(np.float32)
