@@ -426,6 +426,153 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
     row_fwd_post<T, L, E, 1, F>(vv[1], twQ, lds0, lds, Tb, d.nx, i0, t);
 }
 
+// Values derived from the thread index are loop invariant, so the optimiser computes every
+// LDS / global address of the tile loop once, keeps ~40 of them live across it and spills:
+// scratch reloads are vector-memory operations, and one of them inside an FFT (in-order
+// vmcnt) waits for the prefetch it was supposed to overlap with.  Laundering the index at
+// the top of each iteration makes the (cheap) address arithmetic part of the loop body.
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// ------------------------------------------------- row forward, persistent + pipelined
+// Same recipe as k_row_inv_pow2p below (read its comment first): one resident 1024-thread
+// workgroup per CU walks the 8-row tiles; the NEXT tile's image rows are requested into
+// registers as soon as the even-bin spectrum sits in the LDS and land while the two
+// Hermitian post-processing sweeps of the current tile run; every twiddle comes from the
+// LDS (pass table, w_M^n, w_Q^(2m+1) = w_M^m w_Q) so that nothing else queues behind the
+// in-order vmcnt; the post-processing sweep is fully unrolled with clamped block indices
+// (static store count -> the compiler's vmcnt for the prefetched rows is exact).
+template <typename T, int L>
+struct FwdP {
+    static constexpr int E = L / 128;                 // 128 threads per row, 8 rows per workgroup
+    static constexpr int EOK = (E == 8 || E == 16) ? E : 8;
+    using F = RegFft<T, L, EOK, false, 0, true, true>;
+    static constexpr int G = 8;
+    static constexpr int NT = 1024;
+    static constexpr int STRIDE = F::LDS_ELEMS + 4;
+    static constexpr int NVB = FastCfg<T>::NVB;
+    static constexpr int NBE = (L + NVB) / NVB;
+    static constexpr int NBO = L / NVB;
+    static constexpr int BSTEP = NT / G;
+    static constexpr int PTWP = (F::PTWC + 1) & ~1;
+    static constexpr size_t LDS = sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE);
+    // measured: 0.50 -> 0.42 ms at ny = 4096 (x 8 bands of 4096 rows); at ny = 2048 the plain
+    // wave-per-row kernel (E = 16, barrier-free exchanges) is 6 % faster than this one with E = 8
+    static constexpr bool OK = E == 16 && LDS <= (size_t)160 * 1024;
+};
+
+template <typename T, int L, int PAR>
+__device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1,
+                                          cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi) {
+    using P = FwdP<T, L>;
+    using F = typename P::F;
+    constexpr int NVB = P::NVB;
+    constexpr int NBP = PAR ? P::NBO : P::NBE;
+    constexpr int NIT = (NBP + P::BSTEP - 1) / P::BSTEP;
+    cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * NVB;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        int b = bi + k * P::BSTEP;
+        if (b >= NBP) b = NBP - 1;                 // clamped: duplicates of the last block, same data
+        Blk<T, NVB> o;
+#pragma unroll
+        for (int h = 0; h < NVB; ++h) {
+            const int m = NVB * b + h;
+            const bool valid = PAR || m <= L;
+            const int ia = PAR ? m : (m >= L ? 0 : m);
+            const int ib = PAR ? (L - 1 - m) : ((m == 0 || m > L) ? 0 : L - m);
+            cplx<T> w = ltm[m < L ? m : 0];
+            if (PAR) w = w * wq1;
+            else if (m >= L) w = cplx<T>(T(-1), T(0));              // w_Q^(2L) = -1
+            const cplx<T> zv = zr[F::pad(ia)];
+            const cplx<T> zm = zr[F::pad(ib)];
+            o.c[h] = T(0.5) * addrot<false>(addc(zv, zm), w * subc(zv, zm));
+            if (!valid) o.c[h] = cplx<T>(0, 0);
+        }
+        storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
+        __builtin_amdgcn_sched_barrier(0);         // keep the sweeps' LDS reads from piling up (spills)
+    }
+}
+
+template <typename T, int L>
+__global__ void __launch_bounds__(1024)
+k_row_fwd_pow2p(const T* __restrict__ x, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
+                const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
+                cplx<T> wq1) {
+    using P = FwdP<T, L>;
+    using F = typename P::F;
+    constexpr int E = P::EOK, TPB = F::TPB, G = P::G, NT = P::NT;
+    using V2 = typename vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* ltm = ltw + P::PTWP;
+    cplx<T>* lds0 = ltm + L;
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptwc[k];
+    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    V2 xa[E];
+    {
+        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
+        const V2* xr = reinterpret_cast<const V2*>(x + ((size_t)bl * d.nx + (i0 + g)) * d.ny) + t;
+#pragma unroll
+        for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+    }
+    __syncthreads();                                    // tables visible
+    for (;;) {
+        const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
+        cplx<T> vv[2][E];
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                vv[0][j] = cplx<T>(xa[j].x, xa[j].y);            // z[n] = x[2n] + i x[2n+1]
+                vv[1][j] = vv[0][j] * ltm[t + TPB * j];          // z .* w_M^n  (odd bins)
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            F::template runN<false, 2>(vv, lds, t, ltw);
+        }
+        {   // fresh index: nothing thread-derived stays live (and gets spilled) across the FFT
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            __syncthreads();                                     // last exchange's readers are done
+            cplx<T>* wp = lds0 + (size_t)g * P::STRIDE + F::pad(t);
+#pragma unroll
+            for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[0][j];
+            // next tile's rows: in flight during both post-processing sweeps
+            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+            const V2* xr = reinterpret_cast<const V2*>(x + ((size_t)bln * d.nx + (i0n + g)) * d.ny) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+            __syncthreads();
+        }
+        {
+            const int tid = launder((int)threadIdx.x);
+            fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+        }
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            cplx<T>* wp = lds0 + (size_t)g * P::STRIDE + F::pad(t);
+            __syncthreads();                                     // even-bin sweep has read the rows
+#pragma unroll
+            for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[1][j];
+            __syncthreads();
+            fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            __syncthreads();                                     // rows free for the next transform
+        }
+        if (vbn == vb) break;
+        vb = vbn;
+    }
+}
+
 // ------------------------------------------------------------------- row inverse
 // one parity of the inverse row transform: gathers Y[2m + PAR][i0 .. i0+G) (G*8-byte
 // pieces), LDS-transposes them to per-row order, builds the packed spectrum and runs
@@ -658,16 +805,6 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
     }
 }
 
-// Values derived from the thread index are loop invariant, so the optimiser computes every
-// LDS / global address of the tile loop once, keeps ~40 of them live across it and spills:
-// scratch reloads are vector-memory operations, and one of them inside an FFT (in-order
-// vmcnt) waits for the prefetch it was supposed to overlap with.  Laundering the index at
-// the top of each iteration makes the (cheap) address arithmetic part of the loop body.
-__device__ __forceinline__ int launder(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
-
 // MODE 0: no inner products; 1: <x, out>, <out, out>; 2: also <dot_with2, out> (the PCG call)
 template <typename T, int L, int E, int MODE>
 __global__ void __launch_bounds__((InvP<T, L, E>::NT))
@@ -793,6 +930,8 @@ struct FastTables {            // device tables owned by the plan (stored behind
     void* ptw_row_inv;         // inverse row kernel (E = 8): COMPACT table, copied to LDS
     void* twM;                 // exp(-2 pi i n / M), n < L
     int col_persistent;        // PFB_COL_PERSIST (default: auto by size): persistent prefetching column kernel
+    void* ptwc_row_fwd;        // compact pass table of the persistent forward row kernel (its own E)
+    int fwd_persistent;        // PFB_FWD_PERSIST (default 1): persistent pipelined forward row kernel where it fits
     int inv_persistent;        // PFB_INV_PERSIST (default 1): persistent pipelined inverse row kernel where it fits
     int num_cu;
 };
@@ -834,6 +973,17 @@ static int set_invp_attr() {
     return PFB_OK;
 }
 
+template <typename T, int L>
+static int prep_fwdp(void** table) {
+    if constexpr (FwdP<T, L>::OK) {
+        int rc = prep_ptw_compact<T, L, FwdP<T, L>::EOK>(table);
+        if (rc != PFB_OK) return rc;
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2p<T, L>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    return PFB_OK;
+}
+
 // size switch helpers -------------------------------------------------------------
 #define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 
@@ -862,7 +1012,8 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, RowCfg<T, NN, true>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) rc = set_invp_attr<T, NN>(); break;
+        if (rc == PFB_OK) rc = set_invp_attr<T, NN>();                                               \
+        if (rc == PFB_OK) rc = prep_fwdp<T, NN>(&ft->ptwc_row_fwd); break;
         PFB_POW2_SIZES(X)
 #undef X
         default: break;
@@ -917,6 +1068,8 @@ int pow2_prepare(pfb_conv_plan* p) {
     // 2048^2 x 8), the plain 2-workgroup/CU kernel at 4096 (1.17 vs 1.22 ms); 0 / 1 force one
     ft->col_persistent = -1;
     if (const char* e = getenv("PFB_COL_PERSIST")) ft->col_persistent = atoi(e) ? 1 : 0;
+    ft->fwd_persistent = 1;
+    if (const char* e = getenv("PFB_FWD_PERSIST")) ft->fwd_persistent = atoi(e) ? 1 : 0;
     ft->inv_persistent = 1;
     if (const char* e = getenv("PFB_INV_PERSIST")) ft->inv_persistent = atoi(e) ? 1 : 0;
     int dev = 0;
@@ -935,6 +1088,7 @@ void pow2_release(pfb_conv_plan* p) {
     if (ft->ptw_row) (void)hipFree(ft->ptw_row);
     if (ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv);
     if (ft->twM) (void)hipFree(ft->twM);
+    if (ft->ptwc_row_fwd) (void)hipFree(ft->ptwc_row_fwd);
     free(ft);
     p->fast_tables = nullptr;
 }
@@ -993,6 +1147,19 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, in
     using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
+    if constexpr (FwdP<T, L>::OK) {
+        if (ft->fwd_persistent && !beam) {
+            using FP = FwdP<T, L>;
+            const int tiles_per_band = p->nx / FP::G, ntiles = tiles_per_band * nb;
+            const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
+            const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
+            const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
+            hipLaunchKernelGGL((k_row_fwd_pow2p<T, L>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
+                               (cplx<T>*)p->T, (const cplx<T>*)ft->twM, (const cplx<T>*)ft->ptwc_row_fwd, d,
+                               band0, tiles_per_band, ntiles, wq1);
+            return;
+        }
+    }
     const size_t lds = sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
     hipLaunchKernelGGL((k_row_fwd_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const T*)x, (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)p->twQ,
