@@ -88,6 +88,43 @@ def hessian_psf_cube(xpad, xhat, xout, beam, psfhat, lastsize, x,
     return xout + x * sigmainv
 
 
+class hessian_psf_slice:
+    """hessian.py:161-251: the per-band stateful operator.  `ds` is anything with the
+    reference dataset's variables (`.values`) -- DIRTY, PSFHAT, PSF, BEAM, WSUM and optionally
+    MODEL, DUAL, RESIDUAL -- and `bandid`.  __call__ = _hessian_psf_slice with the wsum given
+    to set_wsum (the TOTAL wsum, not the band's).  compute_residual is visibility space
+    (wgridder) and outside the hot path."""
+
+    def __init__(self, ds, nbasis, nmax, nthreads, sigmainv, cell=None, do_wgridding=None,
+                 epsilon=None, double_accum=None):
+        self.nthreads, self.sigmainv = nthreads, sigmainv
+        self.lastsize = ds.PSF.shape[-1]
+        self.bandid = ds.bandid
+        self.dirty = np.ascontiguousarray(ds.DIRTY.values)
+        self.psfhat = np.ascontiguousarray(ds.PSFHAT.values)
+        self.psf = np.ascontiguousarray(ds.PSF.values)
+        self.beam = np.ascontiguousarray(ds.BEAM.values)
+        self.wsumb = ds.WSUM.values[0]
+        self.model = np.ascontiguousarray(ds.MODEL.values) if 'MODEL' in ds else np.zeros_like(self.dirty)
+        if 'DUAL' in ds:
+            self.dual = np.ascontiguousarray(ds.DUAL.values)
+            assert self.dual.shape == (nbasis, nmax)
+        else:
+            self.dual = np.zeros((nbasis, nmax), dtype=self.dirty.dtype)
+        self.residual = np.ascontiguousarray(ds.RESIDUAL.values) if 'RESIDUAL' in ds else self.dirty.copy()
+        self.xout = np.empty(self.dirty.shape, dtype=self.dirty.dtype)
+        self.xhat = np.empty(self.psfhat.shape, dtype=self.psfhat.dtype)
+        self.xpad = np.empty(self.psf.shape, dtype=self.psf.dtype)
+
+    def __call__(self, x):
+        return _hessian_psf_slice(self.xpad, self.xhat, self.xout, self.psfhat, self.beam,
+                                  self.lastsize, x, nthreads=self.nthreads, sigmainv=self.sigmainv,
+                                  wsum=self.wsum)
+
+    def set_wsum(self, wsum):
+        self.wsum = wsum
+
+
 def make_scratch(psfhat, lastsize, shape, dtype):
     """Allocate (xpad, xhat, xout) the way the workers do
     (pcg.py:270-275, spotless.py:176-180), minus make_noncritical."""

@@ -8,6 +8,7 @@ Test infrastructure (see oracle/__init__.py).  Follows
   pfb/opt/power_method.py:11-49    power_method
   pfb/opt/primal_dual.py:91-180    primal_dual_optimised
   pfb/utils/misc.py:1070-1080      l1reweight_func
+  pfb/opt/pcg.py:363-420           pcg_dist (per-band variant, disabled in the live workers)
 
 The recurrences are written out in full so the
 semantics that matter for parity are visible: residual sign r = A x - b, the
@@ -133,6 +134,46 @@ def cg(A, b, x0=None, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
         rnorm = rnorm_next
         eps = rnorm
         k += 1
+    return x
+
+
+def pcg_dist(A, maxit, minit, tol, sigmainv):
+    """pcg.py:363-420.  Differs from pcg(): b = A.residual/A.wsum (A.dirty if there is no
+    residual), x0 = 0, M = x/sigmainv always, eps = rnorm/eps0 with eps0 the INITIAL <r,y>
+    (1.0 if that is NaN or 0), a stall counter (|eps - epsp| < 1e-3 tol, five times) joins the
+    stopping rule, rnorm is re-evaluated from the current r, y at the top of each iteration."""
+    b = (A.residual if hasattr(A, 'residual') else A.dirty) / A.wsum
+    x = np.zeros_like(b)
+    r = A(x) - b
+    y = r / sigmainv
+    p = -y
+    rnorm = np.vdot(r, y)
+    eps0 = 1.0 if (np.isnan(rnorm) or rnorm == 0.0) else rnorm
+    k, eps, stall = 0, 1.0, 0
+    while (eps > tol or k < minit) and k < maxit and stall < 5:
+        xp, rp, epsp = x.copy(), r.copy(), eps
+        Ap = A(p)
+        rnorm = np.vdot(r, y)
+        alpha = rnorm / np.vdot(p, Ap)
+        x = xp + alpha * p
+        r = rp + alpha * Ap
+        y = r / sigmainv
+        rnorm_next = np.vdot(r, y)
+        while rnorm_next > rnorm:
+            alpha *= 0.75
+            x = xp + alpha * p
+            r = rp + alpha * Ap
+            y = r / sigmainv
+            rnorm_next = np.vdot(r, y)
+        beta = rnorm_next / rnorm
+        p = beta * p - y
+        if not np.any(p):
+            break
+        rnorm = rnorm_next
+        k += 1
+        eps = rnorm / eps0
+        if np.abs(eps - epsp) < 1e-3 * tol:
+            stall += 1
     return x
 
 

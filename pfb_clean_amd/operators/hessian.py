@@ -59,6 +59,53 @@ class HessianPsf:
         return res.cpu().numpy() if _dev.is_numpy(x) else res
 
 
+class hessian_psf_slice:
+    """pfb/operators/hessian.py:161-251 -- the per-band stateful operator (only referenced
+    from the commented-out distributed spotless, workers/spotless.py:439-520).
+    Same constructor signature and attributes; the image-space members live on the GPU
+    (torch tensors), `__call__` is _hessian_psf_slice through the band's own plan with the
+    wsum given to set_wsum.  `ds` is the reference's per-band dataset or anything exposing the
+    same variables with `.values` (DIRTY, PSFHAT, PSF, BEAM, WSUM [, MODEL, DUAL, RESIDUAL])
+    and `bandid`.  compute_residual is visibility space (wgridder) -- outside this package."""
+
+    def __init__(self, ds, nbasis, nmax, nthreads, sigmainv, cell=None, do_wgridding=None,
+                 epsilon=None, double_accum=None):
+        self.nthreads = nthreads
+        self.sigmainv = sigmainv
+        self.cell, self.do_wgridding, self.epsilon, self.double_accum = cell, do_wgridding, epsilon, double_accum
+        self.lastsize = ds.PSF.shape[-1]
+        self.bandid = ds.bandid
+        self.dirty = _dev.to_dev(ds.DIRTY.values).contiguous()
+        rdt = self.dirty.dtype
+        self.psfhat = _dev.to_dev(ds.PSFHAT.values).contiguous()
+        self.psf = _dev.to_dev(ds.PSF.values, rdt).contiguous()
+        self.beam = _dev.to_dev(ds.BEAM.values, rdt).contiguous()
+        self.wsumb = ds.WSUM.values[0]
+        self.model = (_dev.to_dev(ds.MODEL.values, rdt).contiguous() if 'MODEL' in ds
+                      else torch.zeros_like(self.dirty))
+        if 'DUAL' in ds:
+            self.dual = _dev.to_dev(ds.DUAL.values, rdt).contiguous()
+            assert tuple(self.dual.shape) == (nbasis, nmax)
+        else:
+            self.dual = torch.zeros((nbasis, nmax), dtype=rdt, device=self.dirty.device)
+        self.residual = (_dev.to_dev(ds.RESIDUAL.values, rdt).contiguous() if 'RESIDUAL' in ds
+                         else self.dirty.clone())
+        nx, ny = self.dirty.shape
+        self._op = HessianPsf(self.psfhat, nx, ny, self.lastsize, beam=self.beam, sigmainv=sigmainv)
+
+    def __call__(self, x):
+        self._op.wsum = None if self.wsum is None else float(self.wsum)
+        self._op.sigmainv = float(self.sigmainv)
+        return self._op(x)
+
+    def compute_residual(self, x):
+        raise NotImplementedError("visibility-space residual (wgridder) is outside the PSF-convolution "
+                                  "hot path; use the reference's _hessian_impl")
+
+    def set_wsum(self, wsum):
+        self.wsum = wsum
+
+
 def _hess(psfhat, beam, lastsize, x, xout, sigmainv, wsum):
     xd = _dev.to_dev(x)
     nx, ny = xd.shape[-2:]

@@ -257,6 +257,75 @@ def _pcg_generic(A, b, x0, M, tol, maxit, minit, verbosity, report_freq, backtra
     return host(x), host(r)
 
 
+def pcg_dist(A, maxit, minit, tol, sigmainv):
+    """pfb/opt/pcg.py:363-420 -- the per-band PCG variant of the (commented-out) distributed
+    spotless: b = A.residual/A.wsum (A.dirty without a residual), x0 = 0, M = x/sigmainv,
+    eps = rnorm/eps0 with eps0 the INITIAL <r, y>, stall counter in the stopping rule.  A is a
+    hessian_psf_slice (or anything with those attributes, callable on GPU tensors).  All vectors
+    stay on the GPU; the matvec is the fused convolution, the recurrences are pfb_axpby /
+    pfb_dot / pfb_any_nonzero; the scalars the while-conditions need come back per iteration
+    (this path keeps the reference's exact backtracking loop)."""
+    lib = _lib.load()
+    src = A.residual if hasattr(A, 'residual') else A.dirty
+    as_numpy = _dev.is_numpy(src)
+    b = _dev.to_dev(src).contiguous() / float(A.wsum)
+    dt = b.dtype
+    code = _dev.code(dt)
+    n = b.numel()
+    st = _dev.stream
+    ws, out = _dev.scratch()
+
+    def dot(u, v):
+        _lib.check(lib.pfb_dot(code, _dev.ptr(u), _dev.ptr(v), n, _dev.ptr(out), _dev.ptr(ws), st()))
+        return out[0].item()
+
+    def anynz(u):
+        _lib.check(lib.pfb_any_nonzero(code, _dev.ptr(u), n, _dev.ptr(out), _dev.ptr(ws), st()))
+        return out[0].item() != 0.0
+
+    def axpby(a, u, bb, v):       # v = a*u + bb*v
+        _lib.check(lib.pfb_axpby(code, float(a), _dev.ptr(u), float(bb), _dev.ptr(v), n, st()))
+
+    def callA(v):
+        return _dev.to_dev(A(v), dt).contiguous().clone()
+
+    x = torch.zeros_like(b)
+    r = callA(x)
+    axpby(-1.0, b, 1.0, r)                           # r = A(x) - b
+    y = r / sigmainv
+    p = -y
+    rnorm = dot(r, y)
+    eps0 = 1.0 if (math.isnan(rnorm) or rnorm == 0.0) else rnorm
+    k, eps, stall = 0, 1.0, 0
+    xp, rp = torch.empty_like(x), torch.empty_like(r)
+    while (eps > tol or k < minit) and k < maxit and stall < 5:
+        xp.copy_(x)
+        rp.copy_(r)
+        epsp = eps
+        Ap = callA(p)
+        rnorm = dot(r, y)
+        alpha = rnorm / dot(p, Ap)
+        while True:
+            x.copy_(xp); axpby(alpha, p, 1.0, x)
+            r.copy_(rp); axpby(alpha, Ap, 1.0, r)
+            y = r / sigmainv
+            rnorm_next = dot(r, y)
+            if not rnorm_next > rnorm:
+                break
+            alpha *= 0.75
+        beta = rnorm_next / rnorm
+        axpby(-1.0, y, beta, p)                      # p = beta*p - y
+        if not anynz(p):
+            break
+        rnorm = rnorm_next
+        k += 1
+        eps = rnorm / eps0
+        if abs(eps - epsp) < 1e-3 * tol:
+            stall += 1
+    print(f'Band={getattr(A, "bandid", "?")}, iters{k}, eps={eps}', file=sys.stderr)
+    return x.cpu().numpy() if as_numpy else x
+
+
 def cg(A, b, x0=None, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
     """pfb/opt/pcg.py:12-50 -- the plain CG variant (no preconditioner, no backtracking,
     stopping rule `eps = <r,r> > tol`, unused by the live workers).  Vector work and

@@ -25,8 +25,8 @@ import _refstubs  # noqa: E402
 _refstubs.install(ROOT)
 
 from pfb.operators.psf import psf_convolve_slice, psf_convolve_cube  # noqa: E402
-from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube  # noqa: E402
-from pfb.opt.pcg import pcg, _pcg_psf_impl  # noqa: E402
+from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube, hessian_psf_slice  # noqa: E402
+from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist  # noqa: E402
 from pfb.opt.power_method import power_method  # noqa: E402
 from pfb.opt.primal_dual import primal_dual_optimised  # noqa: E402
 from pfb.operators.psi import Psi  # noqa: E402
@@ -284,7 +284,65 @@ def gen_pd():
     print('pd.npz', len(out))
 
 
+class _Var:
+    """Stand-in for an xarray variable: .values / .dtype / .shape is all hessian.py:161-221 touches."""
+    def __init__(self, a):
+        self.values, self.dtype, self.shape = a, a.dtype, a.shape
+
+
+class _DS(dict):
+    """Stand-in for the per-band xarray dataset (attribute access + `'MODEL' in ds`)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def gen_dist():
+    """The per-band stateful operator class hessian_psf_slice (hessian.py:161-251) driven by
+    pcg_dist (pcg.py:363-420) -- both only referenced from commented-out worker code, kept in the
+    coverage table."""
+    out = {}
+    rng = np.random.default_rng(470)
+    nx, ny, P, Q = 32, 32, 64, 64
+    psfhat = psd_psfhat(rng, 1, P, Q)[0]
+    psf = sfft.irfftn(psfhat, s=(P, Q))
+    truth = np.zeros((nx, ny))
+    truth[10, 12] = 1.0
+    truth[20, 8] = 0.5
+    xpad, xhat, xout = scratch(psfhat, Q, (nx, ny))
+    beam = 0.7 + 0.3 * rng.random((nx, ny))
+    wsumb, wsum = 3.0, 7.5
+    dirty = wsum * (beam * psf_convolve_slice(xpad, xhat, xout, psfhat, Q, beam * truth)
+                    + 1e-3 * rng.standard_normal((nx, ny)))
+    for tag, extra in (('dirty', {}), ('resid', {'RESIDUAL': _Var(0.5 * dirty + 0.01 * rng.standard_normal((nx, ny))),
+                                                  'MODEL': _Var(0.1 * truth)})):
+        ds = _DS(DIRTY=_Var(dirty.copy()), PSFHAT=_Var(wsum * psfhat), PSF=_Var(wsum * psf),
+                 BEAM=_Var(beam.copy()), WSUM=_Var(np.array([wsumb])), UVW=_Var(np.zeros((1, 3))),
+                 WEIGHT=_Var(np.zeros((1, 1))), VIS_MASK=_Var(np.zeros((1, 1), dtype=np.uint8)),
+                 FREQ=_Var(np.ones(1)), bandid=3, **extra)
+        sigmainv = 1e-3
+        A = hessian_psf_slice(ds, 2, 10, 1, sigmainv, 1.0, False, 1e-7, True)
+        A.set_wsum(wsum)
+        probe = rng.standard_normal((nx, ny))
+        out[f'{tag}_Ax'] = A(probe).copy()
+        out[f'{tag}_probe'] = probe
+        for name, (maxit, minit, tol) in (('a', (30, 5, 1e-6)), ('b', (8, 8, 0.0))):
+            out[f'{tag}_x_{name}'] = pcg_dist(A, maxit, minit, tol, sigmainv).copy()
+        out[f'{tag}_model'] = A.model.copy()
+        out[f'{tag}_residual'] = A.residual.copy()
+        out[f'{tag}_dual_shape'] = np.array(A.dual.shape)
+        if 'RESIDUAL' in extra:
+            out['resid_in'] = extra['RESIDUAL'].values
+            out['model_in'] = extra['MODEL'].values
+    out.update(dirty=dirty, psfhat=wsum * psfhat, psf=wsum * psf, beam=beam, wsumb=wsumb, wsum=wsum,
+               sigmainv=1e-3, Q=Q)
+    np.savez_compressed(os.path.join(HERE, 'dist.npz'), **out)
+    print('dist.npz', len(out))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist']
     for w in which:
         globals()['gen_' + w]()

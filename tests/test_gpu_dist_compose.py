@@ -210,3 +210,47 @@ def test_band_sharded_primal_dual_two_ranks_one_gpu():
         assert p.exitcode == 0
     for rank, errs in sorted(q.get(timeout=5) for _ in range(2)):
         assert max(errs) < 1e-9, (rank, errs)
+
+
+@pytest.mark.parametrize('tag', ['dirty', 'resid'])
+def test_hessian_psf_slice_class_and_pcg_dist(tag):
+    """SURVEY 8a rows a5 / a8 (hessian.py:161-251, pcg.py:363-420) against the REFERENCE's
+    outputs in tests/golden/dist.npz, fp64, GPU resident."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.hessian import hessian_psf_slice
+    from pfb_clean_amd.opt.pcg import pcg_dist
+
+    class _Var:
+        def __init__(self, a):
+            self.values, self.dtype, self.shape = a, a.dtype, a.shape
+
+    class _DS(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    def dist_dataset(g, tag, wrap):
+        extra = {}
+        if tag == 'resid':
+            extra = {'RESIDUAL': _Var(wrap(g['resid_in'])), 'MODEL': _Var(wrap(g['model_in']))}
+        return _DS(DIRTY=_Var(wrap(g['dirty'])), PSFHAT=_Var(wrap(g['psfhat'])), PSF=_Var(wrap(g['psf'])),
+                   BEAM=_Var(wrap(g['beam'])), WSUM=_Var(np.array([float(g['wsumb'])])), bandid=3, **extra)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dist.npz'))
+    dev = torch.device('cuda')
+    A = hessian_psf_slice(dist_dataset(g, tag, wrap=lambda a: torch.from_numpy(np.array(a)).to(dev)),
+                          2, 10, 1, float(g['sigmainv']), 1.0, False, 1e-7, True)
+    A.set_wsum(float(g['wsum']))
+    probe = torch.from_numpy(g[f'{tag}_probe']).to(dev)
+    assert np.abs(A(probe).cpu().numpy() - g[f'{tag}_Ax']).max() < 1e-11 * np.abs(g[f'{tag}_Ax']).max()
+    assert torch.equal(A.model.cpu(), torch.from_numpy(g[f'{tag}_model']))
+    assert torch.equal(A.residual.cpu(), torch.from_numpy(g[f'{tag}_residual']))
+    assert tuple(A.dual.shape) == tuple(g[f'{tag}_dual_shape'])
+    for name, (maxit, minit, tol) in (('a', (30, 5, 1e-6)), ('b', (8, 8, 0.0))):
+        x = pcg_dist(A, maxit, minit, tol, float(g['sigmainv']))
+        ref = g[f'{tag}_x_{name}']
+        assert np.abs(x.cpu().numpy() - ref).max() < 1e-8 * np.abs(ref).max()
+    with pytest.raises(NotImplementedError):
+        A.compute_residual(probe)

@@ -310,3 +310,40 @@ def test_primal_dual_trajectory(golden):
                                         nu=len(bases), tol=0.0, maxit=maxit, positivity=pos)
         assert_allclose(x, g[f'{tag}_x'], rtol=1e-9, atol=1e-12)
         assert_allclose(v, g[f'{tag}_v'], rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------- per-band stateful operator + pcg_dist (a5, a8)
+class _Var:
+    def __init__(self, a):
+        self.values, self.dtype, self.shape = a, a.dtype, a.shape
+
+
+class _DS(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def dist_dataset(g, tag, wrap=lambda a: a):
+    extra = {}
+    if tag == 'resid':
+        extra = {'RESIDUAL': _Var(wrap(g['resid_in'])), 'MODEL': _Var(wrap(g['model_in']))}
+    return _DS(DIRTY=_Var(wrap(g['dirty'])), PSFHAT=_Var(wrap(g['psfhat'])), PSF=_Var(wrap(g['psf'])),
+               BEAM=_Var(wrap(g['beam'])), WSUM=_Var(np.array([float(g['wsumb'])])), bandid=3, **extra)
+
+
+@pytest.mark.parametrize('tag', ['dirty', 'resid'])
+def test_hessian_psf_slice_class_and_pcg_dist(golden, tag):
+    """hessian.py:161-251 + pcg.py:363-420 against the reference's own outputs."""
+    g = golden('dist')
+    A = fc.hessian_psf_slice(dist_dataset(g, tag), 2, 10, 1, float(g['sigmainv']))
+    A.set_wsum(float(g['wsum']))
+    assert_allclose(A(g[f'{tag}_probe']), g[f'{tag}_Ax'], rtol=1e-11, atol=1e-13)
+    assert_allclose(A.model, g[f'{tag}_model'])
+    assert_allclose(A.residual, g[f'{tag}_residual'])
+    assert tuple(A.dual.shape) == tuple(g[f'{tag}_dual_shape'])
+    for name, (maxit, minit, tol) in (('a', (30, 5, 1e-6)), ('b', (8, 8, 0.0))):
+        x = sv.pcg_dist(A, maxit, minit, tol, float(g['sigmainv']))
+        assert_allclose(x, g[f'{tag}_x_{name}'], rtol=1e-8, atol=1e-11)
