@@ -9,6 +9,9 @@ Test infrastructure (see oracle/__init__.py).  Follows
   pfb/opt/primal_dual.py:91-180    primal_dual_optimised
   pfb/utils/misc.py:1070-1080      l1reweight_func
   pfb/opt/pcg.py:363-420           pcg_dist (per-band variant, disabled in the live workers)
+  pfb/utils/misc.py:664-739        dds2cubes (cube assembly; PARITY UNPINNED: its module imports ~20
+                                   absent packages and builds dask graphs, so no golden vector could be
+                                   generated -- restated from the source text)
 
 The recurrences are written out in full so the
 semantics that matter for parity are visible: residual sign r = A x - b, the
@@ -21,6 +24,54 @@ from . import prox as _prox
 
 
 # --------------------------------------------------------------------- misc
+def dds2cubes(dds, nband, apparent=False, dual=True, modelname='MODEL'):
+    """misc.py:664-739 on in-memory datasets (each `ds` exposes DIRTY, BEAM, WSUM and optionally
+    RESIDUAL, PSF, PSFHAT, DUAL, <modelname> with `.values`, plus `bandid`; `name in ds` works).
+    Several datasets may share a band (they are SUMMED: dirty/residual weighted by the beam unless
+    `apparent`, psf/psfhat plain); model and dual are taken from the LAST dataset of a band;
+    mean_beam = sum(beam*wsum)/wsums[b]; dirty, residual, psf, psfhat are divided by the TOTAL wsum."""
+    d0 = dds[0]
+    rt = d0.DIRTY.values.dtype
+    ct = np.result_type(rt, np.complex64)
+    nx, ny = d0.DIRTY.values.shape
+    dirty = np.zeros((nband, nx, ny), rt)
+    model = np.zeros((nband, nx, ny), rt)
+    residual = np.zeros((nband, nx, ny), rt) if 'RESIDUAL' in d0 else None
+    wsums = np.zeros(nband, rt)
+    psf = psfhat = None
+    if 'PSF' in d0:
+        psf = np.zeros((nband,) + d0.PSF.values.shape, rt)
+        psfhat = np.zeros((nband,) + d0.PSFHAT.values.shape, ct)
+    mean_beam = np.zeros((nband, nx, ny), rt)
+    dualc = np.zeros((nband,) + d0.DUAL.values.shape, rt) if (dual and 'DUAL' in d0) else None
+    for ds in dds:
+        b = ds.bandid
+        beam = ds.BEAM.values
+        dirty[b] += ds.DIRTY.values if apparent else ds.DIRTY.values * beam
+        if 'RESIDUAL' in ds:
+            residual[b] += ds.RESIDUAL.values if apparent else ds.RESIDUAL.values * beam
+        if 'PSF' in ds:
+            psf[b] += ds.PSF.values
+            psfhat[b] += ds.PSFHAT.values
+        if modelname in ds:
+            model[b] = ds[modelname].values
+        if dual and 'DUAL' in ds:
+            dualc[b] = ds.DUAL.values
+        mean_beam[b] += beam * ds.WSUM.values[0]
+        wsums[b] += ds.WSUM.values[0]
+    wsum = wsums.sum()
+    dirty /= wsum
+    if residual is not None:
+        residual /= wsum
+    if psf is not None:
+        psf /= wsum
+        psfhat /= wsum
+    for b in range(nband):
+        if wsums[b]:
+            mean_beam[b] /= wsums[b]
+    return dirty, model, residual, psf, psfhat, mean_beam, wsums, dualc
+
+
 def norm_diff(x, xp):
     """misc.py:1326-1351: sqrt(sum((x-xp)^2) / (1e-12 + sum(x^2))), float64
     accumulators, 2-D or 3-D input only."""

@@ -3,6 +3,7 @@ The three pfb/utils/misc.py helpers that sit on the hot path.
 
     norm_diff(x, xp)                      misc.py:1316-1351
     l1reweight_func(psiH, outvar, ...)    misc.py:1070-1080
+    dds2cubes(dds, nband, ...)            misc.py:664-739   (cube assembly, device resident)
 """
 import math
 
@@ -53,3 +54,62 @@ def l1reweight_func(psiH, outvar, rmsfactor, rms_comps, model, alpha=4, group=No
     mcomps = torch.abs(torch.sum(outvar, dim=0))
     rc = rms_comps if not _dev.is_numpy(rms_comps) else torch.as_tensor(rms_comps, device=outvar.device)
     return (1 + rmsfactor) / (1 + mcomps ** alpha / rc ** alpha)
+
+
+def dds2cubes(dds, nband, apparent=False, dual=True, modelname='MODEL'):
+    """pfb/utils/misc.py:664-739 -- assembles the image cubes the solvers work on, here as
+    DEVICE-RESIDENT tensors (no dask graph): returns
+    `(dirty, model, residual, psf, psfhat, mean_beam, wsums, dual)` with the reference's
+    normalisation (dirty/residual beam-weighted unless `apparent` and, like psf/psfhat, divided by
+    the TOTAL wsum; mean_beam = sum(beam*wsum)/wsums[band]; datasets sharing a band are summed,
+    model/dual come from the band's last dataset; absent variables give None).  `dds` is a list of
+    the reference's per-band datasets or of anything exposing DIRTY, BEAM, WSUM [, RESIDUAL, PSF,
+    PSFHAT, DUAL, <modelname>] with `.values` (numpy or tensors), `bandid`, `name in ds` and
+    `ds[name]`.  Reading the `.dds` zarr store itself stays with xarray/zarr (not in this image)."""
+    dev = _dev.require_device()
+    d0 = dds[0]
+    first = _dev.to_dev(d0.DIRTY.values)
+    rt = first.dtype
+    ct = torch.complex64 if rt == torch.float32 else torch.complex128
+    nx, ny = first.shape
+
+    def get(ds, name, dt=rt):
+        return _dev.to_dev(ds[name].values, dt)
+
+    dirty = torch.zeros((nband, nx, ny), dtype=rt, device=dev)
+    model = torch.zeros_like(dirty)
+    residual = torch.zeros_like(dirty) if 'RESIDUAL' in d0 else None
+    wsums = torch.zeros(nband, dtype=rt, device=dev)
+    psf = psfhat = None
+    if 'PSF' in d0:
+        psf = torch.zeros((nband,) + tuple(d0['PSF'].values.shape), dtype=rt, device=dev)
+        psfhat = torch.zeros((nband,) + tuple(d0['PSFHAT'].values.shape), dtype=ct, device=dev)
+    mean_beam = torch.zeros_like(dirty)
+    dualc = (torch.zeros((nband,) + tuple(d0['DUAL'].values.shape), dtype=rt, device=dev)
+             if (dual and 'DUAL' in d0) else None)
+    for ds in dds:
+        b = ds.bandid
+        beam = get(ds, 'BEAM')
+        w = float(ds['WSUM'].values[0])
+        dirty[b] += get(ds, 'DIRTY') if apparent else get(ds, 'DIRTY') * beam
+        if 'RESIDUAL' in ds:
+            residual[b] += get(ds, 'RESIDUAL') if apparent else get(ds, 'RESIDUAL') * beam
+        if 'PSF' in ds:
+            psf[b] += get(ds, 'PSF')
+            psfhat[b] += get(ds, 'PSFHAT', ct)
+        if modelname in ds:
+            model[b] = get(ds, modelname)
+        if dual and 'DUAL' in ds:
+            dualc[b] = get(ds, 'DUAL')
+        mean_beam[b] += beam * w
+        wsums[b] += w
+    wsum = wsums.sum()
+    dirty /= wsum
+    if residual is not None:
+        residual /= wsum
+    if psf is not None:
+        psf /= wsum
+        psfhat /= wsum
+    nz = wsums != 0
+    mean_beam[nz] /= wsums[nz][:, None, None]
+    return dirty, model, residual, psf, psfhat, mean_beam, wsums, dualc

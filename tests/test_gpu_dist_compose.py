@@ -254,3 +254,22 @@ def test_hessian_psf_slice_class_and_pcg_dist(tag):
         assert np.abs(x.cpu().numpy() - ref).max() < 1e-8 * np.abs(ref).max()
     with pytest.raises(NotImplementedError):
         A.compute_residual(probe)
+
+
+@pytest.mark.parametrize('apparent', [False, True])
+def test_dds2cubes_device_loader(apparent):
+    """device-resident cube assembly (misc.py:664-739) against the oracle restatement
+    (parity unpinned by a reference fixture, see oracle/solvers.py)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import dds2cubes
+    from test_oracle_golden import make_dds
+    ref = osv.dds2cubes(make_dds(np.random.default_rng(5)), 3, apparent=apparent)
+    dev = torch.device('cuda')
+    got = dds2cubes(make_dds(np.random.default_rng(5), wrap=lambda a: torch.from_numpy(a).to(dev)), 3,
+                    apparent=apparent)
+    for r, g_ in zip(ref, got):
+        assert g_.is_cuda
+        assert np.abs(g_.cpu().numpy() - r).max() <= 1e-13 * max(1.0, np.abs(r).max())
+    got = dds2cubes(make_dds(np.random.default_rng(5), with_resid=False, with_dual=False), 3)
+    assert got[2] is None and got[7] is None and got[0].is_cuda       # numpy datasets in, tensors out

@@ -347,3 +347,44 @@ def test_hessian_psf_slice_class_and_pcg_dist(golden, tag):
     for name, (maxit, minit, tol) in (('a', (30, 5, 1e-6)), ('b', (8, 8, 0.0))):
         x = sv.pcg_dist(A, maxit, minit, tol, float(g['sigmainv']))
         assert_allclose(x, g[f'{tag}_x_{name}'], rtol=1e-8, atol=1e-11)
+
+
+def make_dds(rng, nband=3, nx=12, ny=10, with_resid=True, with_dual=True, wrap=lambda a: a):
+    """Three datasets: two share band 0, one sits in band 1, band 2 stays empty."""
+    dds = []
+    for bandid, w in ((0, 2.0), (1, 3.5), (0, 1.5)):
+        P, Q = 2 * nx, 2 * ny
+        d = dict(DIRTY=_Var(wrap(rng.standard_normal((nx, ny)))), BEAM=_Var(wrap(0.5 + rng.random((nx, ny)))),
+                 WSUM=_Var(np.array([w])), PSF=_Var(wrap(rng.standard_normal((P, Q)))),
+                 PSFHAT=_Var(wrap(rng.standard_normal((P, Q // 2 + 1)) + 1j * rng.standard_normal((P, Q // 2 + 1)))),
+                 MODEL=_Var(wrap(rng.standard_normal((nx, ny)))), bandid=bandid)
+        if with_resid:
+            d['RESIDUAL'] = _Var(wrap(rng.standard_normal((nx, ny))))
+        if with_dual:
+            d['DUAL'] = _Var(wrap(rng.standard_normal((2, 14, 13))))
+        dds.append(_DS(**d))
+    return dds
+
+
+@pytest.mark.parametrize('apparent', [False, True])
+def test_dds2cubes_oracle_against_definition(apparent):
+    """misc.py:664-739 (parity unpinned: no reference fixture can be generated, see
+    oracle/solvers.py) -- checked against the formulas written out by hand."""
+    rng = np.random.default_rng(5)
+    dds = make_dds(rng)
+    dirty, model, resid, psf, psfhat, mbeam, wsums, dual = sv.dds2cubes(dds, 3, apparent=apparent)
+    a, b, c = dds
+    wsum = 2.0 + 3.5 + 1.5
+    wgt = (lambda ds: 1.0) if apparent else (lambda ds: ds.BEAM.values)
+    assert_allclose(wsums, [3.5, 3.5, 0.0])
+    assert_allclose(dirty[0], (a.DIRTY.values * wgt(a) + c.DIRTY.values * wgt(c)) / wsum)
+    assert_allclose(dirty[1], b.DIRTY.values * wgt(b) / wsum)
+    assert_allclose(resid[0], (a.RESIDUAL.values * wgt(a) + c.RESIDUAL.values * wgt(c)) / wsum)
+    assert_allclose(psf[0], (a.PSF.values + c.PSF.values) / wsum)
+    assert_allclose(psfhat[1], b.PSFHAT.values / wsum)
+    assert_allclose(model[0], c.MODEL.values)               # the band's LAST dataset wins
+    assert_allclose(dual[0], c.DUAL.values)
+    assert_allclose(mbeam[0], (a.BEAM.values * 2.0 + c.BEAM.values * 1.5) / 3.5)
+    assert not dirty[2].any() and not mbeam[2].any()
+    out = sv.dds2cubes(make_dds(rng, with_resid=False, with_dual=False), 3, dual=True)
+    assert out[2] is None and out[7] is None
