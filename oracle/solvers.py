@@ -9,6 +9,7 @@ Test infrastructure (see oracle/__init__.py).  Follows
   pfb/opt/primal_dual.py:91-180    primal_dual_optimised
   pfb/utils/misc.py:1070-1080      l1reweight_func
   pfb/opt/pcg.py:363-420           pcg_dist (per-band variant, disabled in the live workers)
+  pfb/opt/pcg.py:139-239           cg_dct (CG over a nested dict of images, unused by the live workers)
   pfb/utils/misc.py:664-739        dds2cubes (cube assembly; PARITY UNPINNED: its module imports ~20
                                    absent packages and builds dask graphs, so no golden vector could be
                                    generated -- restated from the source text)
@@ -186,6 +187,36 @@ def cg(A, b, x0=None, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
         eps = rnorm
         k += 1
     return x
+
+
+def cg_dct(A, b, x, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
+    """pcg.py:139-239: plain CG (no preconditioner, no backtracking) whose unknown is a nested
+    dict {field: {'t..b..': image}}; A maps such a dict to one of the same structure.
+    r = A x - b, eps = <r, r> summed over all leaves, rule `eps > tol and k < maxit`; x's leaves
+    are updated IN PLACE (`a[field][i] += alpha*b[field][i]`).  Returns (x, r)."""
+    def vdot(u, v):
+        return sum(np.vdot(u[f][i], v[f][i]) for f in u for i in u[f])
+    Ax = A(x)
+    r = {f: {i: Ax[f][i] - b[f][i] for i in Ax[f]} for f in Ax}
+    p = {f: {i: -r[f][i] for i in r[f]} for f in r}
+    rnorm = vdot(r, r)
+    eps, k = rnorm, 0
+    while eps > tol and k < maxit:
+        Ap = A(p)
+        alpha = rnorm / vdot(p, Ap)
+        for f in x:
+            for i in x[f]:
+                x[f][i] += alpha * p[f][i]
+                r[f][i] += alpha * Ap[f][i]
+        rnorm_next = vdot(r, r)
+        beta = rnorm_next / rnorm
+        for f in p:
+            for i in p[f]:
+                p[f][i] = beta * p[f][i] - r[f][i]
+        rnorm = rnorm_next
+        eps = rnorm
+        k += 1
+    return x, r
 
 
 def pcg_dist(A, maxit, minit, tol, sigmainv):

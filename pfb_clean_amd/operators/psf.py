@@ -135,15 +135,20 @@ def _fingerprint(psfhat):
 
 
 def plan_for(psfhat, nx, ny, lastsize):
+    """Plan cache for the reference-shaped call sites (a functools.partial re-presents the same
+    psfhat on every call).  numpy arrays are keyed on address + shape + a strided content sample;
+    tensors on data_ptr + shape + version counter, and the cache entry keeps a reference to the
+    tensor so that its memory cannot be freed and re-used by a DIFFERENT psfhat at the same
+    address while the entry lives (clear_plan_cache() releases plans and references)."""
     key = (_fingerprint(psfhat), int(nx), int(ny), int(lastsize))
     with _cache_lock:
-        plan = _cache.get(key)
-        if plan is not None:
+        hit = _cache.get(key)
+        if hit is not None:
             _cache.move_to_end(key)
-            return plan
+            return hit[0]
     plan = PsfConvPlan(psfhat, nx, ny, lastsize)
     with _cache_lock:
-        _cache[key] = plan
+        _cache[key] = (plan, psfhat if isinstance(psfhat, torch.Tensor) else None)
         while len(_cache) > _CACHE_MAX:
             _cache.popitem(last=False)
     return plan

@@ -257,6 +257,81 @@ def _pcg_generic(A, b, x0, M, tol, maxit, minit, verbosity, report_freq, backtra
     return host(x), host(r)
 
 
+def cg_dct(A, b, x, tol=1e-5, maxit=500, verbosity=1, report_freq=10):
+    """pfb/opt/pcg.py:139-239 -- plain CG whose unknown is a nested dict
+    {field: {'t..b..': image}} (distinct fields, no preconditioner, no backtracking; unused by
+    the live workers).  r = A x - b, eps = <r, r> over all leaves, rule
+    `eps > tol and k < maxit`.  Leaves live on the GPU for the whole solve; `A` is called with a
+    dict of GPU tensors when the caller's leaves are tensors, of numpy arrays otherwise, and like
+    the reference the caller's `x` leaves are updated in place.  Returns (x, r)."""
+    lib = _lib.load()
+    as_numpy = _dev.is_numpy(next(iter(next(iter(b.values())).values())))
+    ws, out = _dev.scratch()
+    st = _dev.stream
+
+    def todev(d):
+        return {f: {i: _dev.to_dev(d[f][i]).contiguous() for i in d[f]} for f in d}
+
+    def callA(d):
+        if not as_numpy:
+            return todev(A(d))
+        return todev(A({f: {i: d[f][i].cpu().numpy() for i in d[f]} for f in d}))
+
+    def vdot(u, v):
+        acc = 0.0
+        for f in u:
+            for i in u[f]:
+                t = u[f][i]
+                _lib.check(lib.pfb_dot(_dev.code(t.dtype), _dev.ptr(t), _dev.ptr(v[f][i]), t.numel(),
+                                       _dev.ptr(out), _dev.ptr(ws), st()))
+                acc += out[0].item()
+        return acc
+
+    def axpby(a, u, bb, v):       # v = a*u + bb*v, leaf by leaf
+        for f in v:
+            for i in v[f]:
+                t = v[f][i]
+                _lib.check(lib.pfb_axpby(_dev.code(t.dtype), float(a), _dev.ptr(u[f][i]), float(bb),
+                                         _dev.ptr(t), t.numel(), st()))
+
+    xd = todev(x)
+    if not as_numpy:                 # tensors already on the device are updated in place
+        xd = {f: {i: (x[f][i] if (x[f][i].is_cuda and x[f][i].is_contiguous()) else xd[f][i]) for i in x[f]}
+              for f in x}
+    bd = todev(b)
+    r = callA(xd)
+    r = {f: {i: r[f][i].clone() for i in r[f]} for f in r}
+    axpby(-1.0, bd, 1.0, r)                                   # r = A x - b
+    p = {f: {i: -r[f][i] for i in r[f]} for f in r}
+    rnorm = vdot(r, r)
+    eps, k = rnorm, 0
+    while eps > tol and k < maxit:
+        Ap = callA(p)
+        alpha = rnorm / vdot(p, Ap)
+        axpby(alpha, p, 1.0, xd)                              # x += alpha p
+        axpby(alpha, Ap, 1.0, r)                              # r += alpha Ap
+        rnorm_next = vdot(r, r)
+        beta = rnorm_next / rnorm
+        axpby(-1.0, r, beta, p)                               # p = beta p - r
+        rnorm = rnorm_next
+        eps = rnorm
+        k += 1
+        if not k % report_freq and verbosity > 1:
+            _log(f"At iteration {k} eps = {eps:.3e}", verbosity, 2)
+    if verbosity:
+        _log(f"Max iters reached. eps = {eps:.3e}" if k >= maxit
+             else f"Success, converged after {k} iterations", verbosity)
+    for f in x:                                               # in-place semantics of the reference
+        for i in x[f]:
+            if as_numpy:
+                x[f][i][...] = xd[f][i].cpu().numpy()
+            elif x[f][i] is not xd[f][i]:
+                x[f][i].copy_(xd[f][i])
+    if as_numpy:
+        r = {f: {i: r[f][i].cpu().numpy() for i in r[f]} for f in r}
+    return x, r
+
+
 def pcg_dist(A, maxit, minit, tol, sigmainv):
     """pfb/opt/pcg.py:363-420 -- the per-band PCG variant of the (commented-out) distributed
     spotless: b = A.residual/A.wsum (A.dirty without a residual), x0 = 0, M = x/sigmainv,

@@ -26,7 +26,7 @@ _refstubs.install(ROOT)
 
 from pfb.operators.psf import psf_convolve_slice, psf_convolve_cube  # noqa: E402
 from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube, hessian_psf_slice  # noqa: E402
-from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist  # noqa: E402
+from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist, cg_dct  # noqa: E402
 from pfb.opt.power_method import power_method  # noqa: E402
 from pfb.opt.primal_dual import primal_dual_optimised  # noqa: E402
 from pfb.operators.psi import Psi  # noqa: E402
@@ -342,7 +342,50 @@ def gen_dist():
     print('dist.npz', len(out))
 
 
+def gen_dct():
+    """cg_dct (pcg.py:139-239): plain CG over a nested dict {field: {'t..b..': image}}; here two
+    fields of different size, two time/band keys each, A = per-leaf PSF Hessian + Tikhonov."""
+    out = {}
+    rng = np.random.default_rng(480)
+    shapes = {'f0': (24, 20), 'f1': (16, 32)}
+    keys = ['t0b0', 't0b1']
+    sigmainv = 5e-2
+    ops, b, x = {}, {}, {}
+    for fld, (nx, ny) in shapes.items():
+        ops[fld], b[fld], x[fld] = {}, {}, {}
+        for i in keys:
+            P, Q = 2 * nx, 2 * ny
+            psfhat = psd_psfhat(rng, 1, P, Q)[0]
+            out[f'{fld}_{i}_psfhat'] = psfhat
+            ops[fld][i] = (psfhat, Q, scratch(psfhat, Q, (nx, ny)))
+            b[fld][i] = rng.standard_normal((nx, ny))
+            x[fld][i] = 0.1 * rng.standard_normal((nx, ny))
+            out[f'{fld}_{i}_b'] = b[fld][i].copy()
+            out[f'{fld}_{i}_x0'] = x[fld][i].copy()
+
+    def A(v):
+        res = {}
+        for fld in v.keys():
+            res[fld] = {}
+            for i in v[fld].keys():
+                psfhat, Q, (xpad, xhat, xout) = ops[fld][i]
+                res[fld][i] = _hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, v[fld][i],
+                                                 sigmainv=sigmainv)
+        return res
+
+    for tag, (tol, maxit) in (('it6', (0.0, 6)), ('tol', (1e-3, 200))):
+        x0 = {fld: {i: x[fld][i].copy() for i in keys} for fld in shapes}
+        xs, rs = cg_dct(A, b, x0, tol=tol, maxit=maxit, verbosity=0)
+        for fld in shapes:
+            for i in keys:
+                out[f'{tag}_{fld}_{i}_x'] = xs[fld][i].copy()
+                out[f'{tag}_{fld}_{i}_r'] = rs[fld][i].copy()
+    out['sigmainv'] = sigmainv
+    np.savez_compressed(os.path.join(HERE, 'dct.npz'), **out)
+    print('dct.npz', len(out))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct']
     for w in which:
         globals()['gen_' + w]()

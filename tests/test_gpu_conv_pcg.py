@@ -373,3 +373,26 @@ def test_power_method_golden(amd, golden):
     beta2, b2 = amd.pm.power_method(convt, b0.shape, b0=torch.from_numpy(b0).cuda(), tol=1e-3,
                                     maxit=40, verbosity=0)
     assert abs(beta2 - beta) < 1e-12 * abs(beta) and b2.is_cuda
+
+
+def test_plan_cache_survives_address_reuse(amd):
+    """Two different psfhat TENSORS that end up at the same device address (the first one freed
+    before the second is created) must not share a cached plan."""
+    rng = np.random.default_rng(33)
+    nx = ny = 64
+    P = Q = 128
+    dev = torch.device('cuda')
+    x = rng.standard_normal((1, nx, ny))
+    xt = torch.from_numpy(x).to(dev)
+    amd.psf.clear_plan_cache()
+    outs, refs, ptrs = [], [], []
+    for k in range(3):
+        psfhat = ofc.psfhat_from_psf(rng.standard_normal((1, P, Q)))
+        t = torch.from_numpy(psfhat).to(dev)
+        ptrs.append(t.data_ptr())
+        outs.append(amd.psf.psf_convolve_cube(None, None, None, t, Q, xt).clone())
+        del t
+        xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+        refs.append(ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x).copy())
+    for o, r in zip(outs, refs):
+        assert relerr(o.cpu().numpy(), r) < 1e-12

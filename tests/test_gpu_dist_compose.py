@@ -273,3 +273,36 @@ def test_dds2cubes_device_loader(apparent):
         assert np.abs(g_.cpu().numpy() - r).max() <= 1e-13 * max(1.0, np.abs(r).max())
     got = dds2cubes(make_dds(np.random.default_rng(5), with_resid=False, with_dual=False), 3)
     assert got[2] is None and got[7] is None and got[0].is_cuda       # numpy datasets in, tensors out
+
+
+@pytest.mark.parametrize('kind', ['tensor', 'numpy'])
+def test_cg_dct_nested_dict(kind):
+    """cg_dct on the GPU against the reference's iterates (tests/golden/dct.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.opt.pcg import cg_dct
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    from test_oracle_golden import dct_problem
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'dct.npz'))
+    dev = torch.device('cuda')
+    wrap = (lambda a: torch.from_numpy(np.array(a)).to(dev)) if kind == 'tensor' else (lambda a: np.array(a))
+    shapes, keys, b, _ = dct_problem(g, wrap)
+    ops = {f: {i: HessianPsf(torch.from_numpy(g[f'{f}_{i}_psfhat'][None]).to(dev), shapes[f][0], shapes[f][1],
+                             2 * shapes[f][1], sigmainv=float(g['sigmainv'])) for i in keys} for f in shapes}
+
+    def A(v):
+        return {f: {i: ops[f][i](v[f][i]) for i in v[f]} for f in v}
+    for tag, (tol, maxit) in (('it6', (0.0, 6)), ('tol', (1e-3, 200))):
+        x0 = dct_problem(g, wrap)[3]
+        xs, rs = cg_dct(A, b, x0, tol=tol, maxit=maxit, verbosity=0)
+        assert xs is x0
+        for f in shapes:
+            for i in keys:
+                xv = xs[f][i].cpu().numpy() if kind == 'tensor' else xs[f][i]
+                rv = rs[f][i].cpu().numpy() if kind == 'tensor' else rs[f][i]
+                # 'tol' runs ~100 unpreconditioned CG steps on an ill-conditioned system: rounding
+                # differences between the two FFTs are amplified to ~1e-8 relative
+                rtol = 1e-10 if tag == 'it6' else 1e-6
+                assert np.abs(xv - g[f'{tag}_{f}_{i}_x']).max() < rtol * np.abs(g[f'{tag}_{f}_{i}_x']).max()
+                bmax = np.abs(g[f'{f}_{i}_b']).max()          # the recursive residual has shrunk 1000-fold
+                assert np.abs(rv - g[f'{tag}_{f}_{i}_r']).max() < (1e-10 if tag == 'it6' else 1e-5) * bmax

@@ -388,3 +388,31 @@ def test_dds2cubes_oracle_against_definition(apparent):
     assert not dirty[2].any() and not mbeam[2].any()
     out = sv.dds2cubes(make_dds(rng, with_resid=False, with_dual=False), 3, dual=True)
     assert out[2] is None and out[7] is None
+
+
+def dct_problem(g, wrap=lambda a: a):
+    shapes = {'f0': (24, 20), 'f1': (16, 32)}
+    keys = ['t0b0', 't0b1']
+    b = {f: {i: wrap(g[f'{f}_{i}_b']) for i in keys} for f in shapes}
+    x0 = {f: {i: wrap(g[f'{f}_{i}_x0'].copy()) for i in keys} for f in shapes}
+    return shapes, keys, b, x0
+
+
+def test_cg_dct_golden(golden):
+    """pcg.py:139-239 against the reference's own iterates (tests/golden/dct.npz)."""
+    g = golden('dct')
+    shapes, keys, b, _ = dct_problem(g)
+    sigmainv = float(g['sigmainv'])
+    scr = {f: {i: _scratch(g[f'{f}_{i}_psfhat'], 2 * shapes[f][1], shapes[f]) for i in keys} for f in shapes}
+
+    def A(v):
+        return {f: {i: fc._hessian_psf_slice(*scr[f][i], g[f'{f}_{i}_psfhat'], None, 2 * shapes[f][1], v[f][i],
+                                             sigmainv=sigmainv) for i in v[f]} for f in v}
+    for tag, (tol, maxit) in (('it6', (0.0, 6)), ('tol', (1e-3, 200))):
+        x0 = dct_problem(g)[3]
+        xs, rs = sv.cg_dct(A, b, x0, tol=tol, maxit=maxit, verbosity=0)
+        assert xs is x0
+        for f in shapes:
+            for i in keys:
+                assert_allclose(xs[f][i], g[f'{tag}_{f}_{i}_x'], rtol=1e-8, atol=1e-10)
+                assert_allclose(rs[f][i], g[f'{tag}_{f}_{i}_r'], rtol=1e-7, atol=1e-9)
