@@ -82,6 +82,15 @@ int pfb_psfconv_plan_destroy(pfb_conv_plan* plan);
  * pfb/utils/misc.py:721-723.  Copied into the plan's own layout (once). */
 int pfb_psfconv_set_psfhat(pfb_conv_plan* plan, const void* psfhat, void* stream);
 
+/* Produce psfhat ON THE DEVICE from the real PSF and install it:
+ *   psfhat = r2c(ifftshift(psf), axes=(0,1), forward, unnormalised)
+ * (pfb/operators/gridder.py:712-714 and pfb/utils/fft.py:7-9).  psf: (nband, nx_psf, ny_psf)
+ * real, row-major.  psfhat_out: NULL, or (nband, nx_psf, ny_psf/2+1) complex that also
+ * receives the transform in the reference's layout (e.g. for the DDS PSFHAT variable).
+ * One workgroup transforms one line in LDS, so 2*max(nx_psf, ny_psf/2)*sizeof(complex) must fit
+ * 160 KB (nx_psf <= 10240 fp32 / 5120 fp64); PFB_ERR_UNSUPPORTED beyond that. */
+int pfb_psfconv_set_psf(pfb_conv_plan* plan, const void* psf, void* psfhat_out, void* stream);
+
 /* Apply to bands [band0, band0+nb) of the plan.  x, out: (nb, nx, ny) real; out may
  * not alias x.  beam: (nb, nx, ny) or NULL.  wsum <= 0 means "no division"
  * (reference wsum=None).  sigmainv may be 0.

@@ -19,6 +19,9 @@ PCG_STATUS = {0: 'converged', 1: 'maxit', 2: 'zero-residual', 3: 'breakdown'}
 REDUCE_WS_DOUBLES = 8192
 
 
+PFB_ERR_UNSUPPORTED = -2
+
+
 class PfbHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libpfb_hip: {ERRORS.get(code, code)}: {msg}")
@@ -41,6 +44,7 @@ SIGNATURES = {
     'pfb_psfconv_plan_destroy': (_i, [_vp]),
     'pfb_psfconv_set_psfhat': (_i, [_vp, _vp, _vp]),
     'pfb_psfconv_apply': (_i, [_vp, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
+    'pfb_psfconv_set_psf': (_i, [_vp, _vp, _vp, _vp]),
     'pfb_psfconv_apply_dots': (_i, [_vp, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     'pfb_psfconv_plan_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz)]),
     'pfb_psfconv_set_profiling': (_i, [_vp, _i]),

@@ -171,6 +171,45 @@ k_row_inv_generic(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ tw
     }
 }
 
+// ------------------------------------------------------------- PSFHAT producer
+// psfhat = r2c(ifftshift(psf), axes=(0,1), forward, unnormalised)   (gridder.py:712-714, fft.py:7-9)
+// ifftshift: y[i] = x[(i + n/2) % n] (n/2 rounded down).  One workgroup per line: rows as
+// packed-real transforms of length M = Q/2 (+ Hermitian unpacking), then columns of length P
+// in place -- once per gridding run, so the column pass simply takes the strided 8/16-byte
+// accesses of the caller's (P, M+1) row-major layout.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_psfhat_rows(const T* __restrict__ psf, cplx<T>* __restrict__ out, const cplx<T>* __restrict__ twQ,
+              int P, int Q, FftFactors f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = Q / 2;
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* bufB = bufA + M;
+    const int u = blockIdx.x, band = blockIdx.y;
+    const T* row = psf + ((size_t)band * P + (u + P / 2) % P) * Q;
+    for (int n = threadIdx.x; n < M; n += blockDim.x)
+        bufA[n] = cplx<T>(row[(2 * n + M) % Q], row[(2 * n + 1 + M) % Q]);   // Q/2 = M
+    cplx<T>* Z = fft_lds_generic<T, false>(bufA, bufB, f, twQ, 2);
+    cplx<T>* orow = out + ((size_t)band * P + u) * (M + 1);
+    for (int v = threadIdx.x; v <= M; v += blockDim.x) {
+        const cplx<T> zv = Z[v == M ? 0 : v];
+        const cplx<T> zm = conj(Z[v == 0 ? 0 : M - v]);
+        orow[v] = T(0.5) * ((zv + zm) + mul_mi(twQ[v] * (zv - zm)));
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_psfhat_cols(cplx<T>* __restrict__ out, const cplx<T>* __restrict__ twP, int P, int M1, FftFactors f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* bufB = bufA + P;
+    cplx<T>* col = out + (size_t)blockIdx.y * P * M1 + blockIdx.x;
+    for (int n = threadIdx.x; n < P; n += blockDim.x) bufA[n] = col[(size_t)n * M1];
+    cplx<T>* X = fft_lds_generic<T, false>(bufA, bufB, f, twP, 1);
+    for (int n = threadIdx.x; n < P; n += blockDim.x) col[(size_t)n * M1] = X[n];
+}
+
 // out[q] = sum of the n partials of quantity q (q < nq), fixed order => deterministic
 __global__ void __launch_bounds__(256)
 k_sum_partials(const double* __restrict__ partials, int n, int nq, double* __restrict__ out) {
@@ -242,6 +281,21 @@ static int set_lds_limits(const pfb_conv_plan*) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_generic<T>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_psfhat_rows<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_psfhat_cols<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    return PFB_OK;
+}
+
+template <typename T>
+static int psfhat_from_psf_t(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st) {
+    const size_t lds_r = 2 * sizeof(cplx<T>) * (size_t)p->M, lds_c = 2 * sizeof(cplx<T>) * (size_t)p->P;
+    hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(p->P, p->nband), dim3(256), lds_r, st, (const T*)psf,
+                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twQ, p->P, p->Q, p->frow);
+    hipLaunchKernelGGL((k_psfhat_cols<T>), dim3(p->M + 1, p->nband), dim3(256), lds_c, st,
+                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twP, p->P, p->M + 1, p->fcol);
+    PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
 
@@ -393,6 +447,30 @@ int pfb_psfconv_set_psfhat(pfb_conv_plan* p, const void* psfhat, void* stream) {
     PFB_HIP_CHECK(hipGetLastError());
     p->have_psf = 1;
     return PFB_OK;
+}
+
+int pfb_psfconv_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, void* stream) {
+    PFB_REQUIRE(p && psf, PFB_ERR_INVALID, "set_psf: null argument");
+    const size_t csz = p->dtype == PFB_F32 ? 8 : 16;
+    const size_t lds_need = 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
+    PFB_REQUIRE(lds_need <= 160 * 1024, PFB_ERR_UNSUPPORTED,
+                "set_psf: a (%d,%d) PSF grid needs %zu B of LDS per line (> 160 KB); hand over psfhat instead",
+                p->P, p->Q, lds_need);
+    hipStream_t st = as_stream(stream);
+    void* tmp = nullptr;
+    void* dst = psfhat_out;
+    if (!dst) {
+        PFB_HIP_CHECK(hipMalloc(&tmp, csz * (size_t)p->nband * p->P * (p->M + 1)));
+        dst = tmp;
+    }
+    int rc = p->dtype == PFB_F32 ? psfhat_from_psf_t<float>(p, psf, dst, st)
+                                 : psfhat_from_psf_t<double>(p, psf, dst, st);
+    if (rc == PFB_OK) rc = pfb_psfconv_set_psfhat(p, dst, stream);
+    if (tmp) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+    }
+    return rc;
 }
 
 static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,

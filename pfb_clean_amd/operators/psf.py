@@ -61,6 +61,45 @@ class PsfConvPlan:
     def handle(self):
         return self._h
 
+    @classmethod
+    def from_psf(cls, psf, nx, ny, want_psfhat=False):
+        """Build the plan straight from the real PSF cube (nband, nx_psf, ny_psf) | (nx_psf, ny_psf):
+        psfhat = r2c(ifftshift(psf)) is produced by the library's own kernels
+        (pfb_psfconv_set_psf; gridder.py:712-714) and never leaves the device.  With
+        want_psfhat=True also returns it in the reference's layout.  Raises PfbHipError
+        (unsupported) when a PSF line does not fit the LDS (nx_psf > 10240 fp32 / 5120 fp64)."""
+        lib = _lib.load()
+        p = _dev.to_dev(psf)
+        if p.ndim == 2:
+            p = p[None]
+        if p.ndim != 3 or p.dtype not in (torch.float32, torch.float64):
+            raise ValueError("psf must be a real (nband, nx_psf, ny_psf) or (nx_psf, ny_psf) array")
+        p = p.contiguous()
+        self = cls.__new__(cls)
+        self.nband, self.nx_psf, self.lastsize = (int(v) for v in p.shape)
+        self.nyo2 = self.lastsize // 2 + 1
+        self.nx, self.ny = int(nx), int(ny)
+        self.rdtype = p.dtype
+        self.code = _dev.code(self.rdtype)
+        self.device = p.device
+        h = C.c_void_p()
+        _lib.check(lib.pfb_psfconv_plan_create(self.nx, self.ny, self.nx_psf, self.lastsize,
+                                               self.nband, self.code, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        cdt = torch.complex64 if self.rdtype == torch.float32 else torch.complex128
+        ph = torch.empty((self.nband, self.nx_psf, self.nyo2), dtype=cdt, device=p.device) if want_psfhat else None
+        try:
+            _lib.check(lib.pfb_psfconv_set_psf(h, _dev.ptr(p), _dev.ptr(ph), _dev.stream()))
+        except Exception:
+            self.close()
+            raise
+        torch.cuda.current_stream().synchronize()      # p may be a temporary
+        fast, vb, wsb = C.c_int(), C.c_int(), C.c_size_t()
+        lib.pfb_psfconv_plan_info(h, C.byref(fast), C.byref(vb), C.byref(wsb))
+        self.fast_path, self.vb, self.workspace_bytes = bool(fast.value), vb.value, wsb.value
+        return (self, ph) if want_psfhat else self
+
     def apply(self, x, out=None, beam=None, wsum=None, sigmainv=0.0, band0=0,
               dot_with=None, dot_out=None):
         """out = [beam*]conv([beam*]x)[/wsum] + sigmainv*x on bands

@@ -306,3 +306,42 @@ def test_cg_dct_nested_dict(kind):
                 assert np.abs(xv - g[f'{tag}_{f}_{i}_x']).max() < rtol * np.abs(g[f'{tag}_{f}_{i}_x']).max()
                 bmax = np.abs(g[f'{f}_{i}_b']).max()          # the recursive residual has shrunk 1000-fold
                 assert np.abs(rv - g[f'{tag}_{f}_{i}_r']).max() < (1e-10 if tag == 'it6' else 1e-5) * bmax
+
+
+@pytest.mark.parametrize('rdt', [np.float64, np.float32])
+@pytest.mark.parametrize('shape', [(2, 128, 128), (1, 96, 80), (2, 60, 100), (1, 45, 66), (1, 512, 2048)])
+def test_native_psfhat_producer(shape, rdt):
+    """pfb_psfconv_set_psf (gridder.py:712-714: r2c(ifftshift(psf))) against the oracle, pow2 and
+    mixed-radix grids, odd nx_psf; and a plan built straight from the PSF convolves like one built
+    from the oracle's psfhat."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.fft import psfhat_from_psf
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    rng = np.random.default_rng(shape[1] + shape[2])
+    psf = rng.standard_normal(shape).astype(rdt)
+    ref = ofc.psfhat_from_psf(psf.astype(np.float64))
+    got = psfhat_from_psf(psf)
+    tol = 1e-12 if rdt == np.float64 else 2e-6
+    assert got.shape == ref.shape and got.dtype == (np.complex128 if rdt == np.float64 else np.complex64)
+    assert np.abs(got - ref).max() < tol * np.abs(ref).max()
+    assert np.abs(psfhat_from_psf(psf[0]) - ref[0]).max() < tol * np.abs(ref).max()       # 2-D input
+    nb, P, Q = shape
+    nx, ny = P // 2, Q // 2
+    dev = torch.device('cuda')
+    plan, ph = PsfConvPlan.from_psf(torch.from_numpy(psf).to(dev), nx, ny, want_psfhat=True)
+    assert np.abs(ph.cpu().numpy() - ref).max() < tol * np.abs(ref).max()
+    x = rng.standard_normal((nb, nx, ny)).astype(rdt)
+    xpad, xhat, xout = ofc.make_scratch(ref, Q, x.shape, np.float64)
+    want = ofc.psf_convolve_cube(xpad, xhat, xout, ref, Q, x.astype(np.float64))
+    y = plan.apply(torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.abs(y - want).max() < (1e-12 if rdt == np.float64 else 1e-5) * np.abs(want).max()
+    plan.close()
+
+
+def test_psfhat_producer_falls_back_for_odd_last_axis():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.fft import psfhat_from_psf
+    psf = np.random.default_rng(2).standard_normal((1, 30, 33))
+    assert np.abs(psfhat_from_psf(psf) - ofc.psfhat_from_psf(psf)).max() < 1e-11
