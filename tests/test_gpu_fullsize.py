@@ -1,0 +1,115 @@
+"""
+Full-size checks of the hot path at BASELINE's headline workload (4096 x 4096 x 8 bands, fp32,
+nx_psf = ny_psf = 8192) through size-independent properties -- the CPU oracle needs ~1 s per
+band-matvec at this size, so instead of a pointwise comparison:
+
+  * point-source response: A(delta at (i0, j0)) must be the PSF itself, shifted and cropped
+    (exact statement of "convolution with the PSF"; also exercises the native PSFHAT producer
+    at 8192 x 8192),
+  * linearity and, for a symmetric PSF, self-adjointness <y, A x> = <A y, x>,
+  * band sub-ranges (the multi-GPU sharding path, band0 > 0) reproduce the full launch bitwise,
+  * the fused inner products of the convolution epilogue equal separately computed ones,
+  * a fused PCG solve actually reduces the residual of (A + sigma I) x = b.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+N, NB = 4096, 8
+
+
+@pytest.fixture(scope='module')
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(7)
+    P = Q = 2 * N
+    # symmetric, compact PSF per band: a 9 x 9 patch around the centre, psf[c + d] = psf[c - d]
+    K = 4
+    patch = torch.rand((NB, K + 1, K + 1), generator=g, device=dev, dtype=torch.float32)
+    full = torch.zeros((NB, 2 * K + 1, 2 * K + 1), device=dev, dtype=torch.float32)
+    for a in range(-K, K + 1):
+        for b in range(-K, K + 1):
+            full[:, K + a, K + b] = patch[:, abs(a), abs(b)]
+    full[:, K, K] += 90.0                       # diagonally dominant -> the operator is positive definite
+    psf = torch.zeros((NB, P, Q), device=dev, dtype=torch.float32)
+    psf[:, P // 2 - K:P // 2 + K + 1, Q // 2 - K:Q // 2 + K + 1] = full
+    plan = PsfConvPlan.from_psf(psf, N, N)
+    assert plan.fast_path
+    del psf
+    x = torch.randn((NB, N, N), generator=g, device=dev, dtype=torch.float32)
+    y = torch.randn((NB, N, N), generator=g, device=dev, dtype=torch.float32)
+    yield plan, full, x, y, K
+    plan.close()
+
+
+def test_point_source_response_is_the_psf(setup):
+    plan, full, x, y, K = setup
+    d = torch.zeros_like(x)
+    spots = [(0, 0), (N - 1, N - 1), (5, 4090), (2048, 2047), (4095, 0), (1000, 3000), (17, 17), (4000, 100)]
+    for b, (i0, j0) in enumerate(spots):
+        d[b, i0, j0] = 1.0
+    out = plan.apply(d)
+    for b, (i0, j0) in enumerate(spots):
+        want = torch.zeros((N, N), device=x.device, dtype=torch.float32)
+        for a in range(-K, K + 1):
+            for c in range(-K, K + 1):
+                i, j = i0 + a, j0 + c
+                if 0 <= i < N and 0 <= j < N:
+                    want[i, j] = full[b, K + a, K + c]
+        err = (out[b] - want).abs().max().item()
+        assert err < 2e-5 * full[b].abs().max().item(), (b, err)
+
+
+def test_linearity_and_self_adjointness(setup):
+    plan, full, x, y, K = setup
+    Ax, Ay = plan.apply(x), plan.apply(y)
+    comb = plan.apply(0.75 * x - 1.5 * y)
+    scale = Ax.abs().max().item()
+    assert (comb - (0.75 * Ax - 1.5 * Ay)).abs().max().item() < 2e-5 * scale
+    lhs = torch.sum(y.double() * Ax.double()).item()
+    rhs = torch.sum(Ay.double() * x.double()).item()
+    assert abs(lhs - rhs) < 1e-5 * (torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(Ax.double())).item()
+
+
+def test_band_subranges_match_full_launch_bitwise(setup):
+    plan, full, x, y, K = setup
+    whole = plan.apply(x, sigmainv=0.25)
+    for b0, nb in ((0, 4), (4, 4), (7, 1), (2, 3)):
+        part = plan.apply(x[b0:b0 + nb], band0=b0, sigmainv=0.25)
+        assert torch.equal(part, whole[b0:b0 + nb]), (b0, nb)
+
+
+def test_fused_inner_products(setup):
+    from pfb_clean_amd import _lib, _dev
+    plan, full, x, y, K = setup
+    out = torch.empty_like(x)
+    dots = torch.zeros(3, dtype=torch.float64, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, NB, _dev.ptr(x), None, 0.0, 0.1, _dev.ptr(out),
+                                          _dev.ptr(x), _dev.ptr(y), _dev.ptr(dots), _dev.stream()))
+    od = out.double()
+    want = [torch.sum(x.double() * od).item(), torch.sum(y.double() * od).item(), torch.sum(od * od).item()]
+    got = dots.tolist()
+    nrm = torch.linalg.vector_norm(od).item()
+    assert abs(got[0] - want[0]) < 1e-10 * nrm * torch.linalg.vector_norm(x.double()).item()
+    assert abs(got[1] - want[1]) < 1e-10 * nrm * torch.linalg.vector_norm(y.double()).item()
+    assert abs(got[2] - want[2]) < 1e-12 * want[2]
+
+
+def test_fused_pcg_reduces_the_residual(setup):
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    from pfb_clean_amd.opt.pcg import pcg_fused
+    plan, full, x, y, K = setup
+    sig = 0.5
+    A = HessianPsf(plan, N, N, 2 * N, sigmainv=sig)
+    b = A(x)                                            # consistent right-hand side, solution x
+    sol, r, res = pcg_fused(A, b, None, mdiv=sig, tol=1e-6, maxit=40, minit=5)
+    r0 = torch.linalg.vector_norm(b.double()).item()
+    rk = torch.linalg.vector_norm((A(sol) - b).double()).item()
+    assert res.iters >= 5 and rk < 1e-4 * r0
+    assert (sol - x).abs().max().item() < 1e-3 * x.abs().max().item()
