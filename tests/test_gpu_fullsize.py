@@ -149,16 +149,16 @@ def test_psi_full_size_reconstruction_adjoint_and_dual_update():
     lhs = torch.sum(probe.double() * c.double()).item()
     rhs = torch.sum(x.double() * ht.double()).item()
     assert abs(lhs - rhs) < 1e-5 * (torch.linalg.vector_norm(probe.double()) * torch.linalg.vector_norm(c.double())).item()
-    # dual update identity
+    # dual update identity -- in fp64: near the threshold the factor 1 - soft/a is ill-conditioned in
+    # the band sum, so fp32 summation order alone moves individual entries by 1e-4 relative
     lam, sigma = 0.3, 1.7
-    w = torch.rand(a.shape[1:], generator=g, device=dev, dtype=torch.float32)
-    vp = torch.randn(a.shape, generator=g, device=dev, dtype=torch.float32)
-    v = a.clone()
+    w = torch.rand(a.shape[1:], generator=g, device=dev, dtype=torch.float64)
+    vp = torch.randn(a.shape, generator=g, device=dev, dtype=torch.float64)
+    v = a.double()
     vt = vp + sigma * v
     l2 = torch.abs(vt.sum(dim=0) / sigma)
     soft = torch.clamp(l2 - lam * w / sigma, min=0.0)
     ratio = torch.where(l2 != 0, soft / torch.where(l2 != 0, l2, torch.ones_like(l2)), torch.zeros_like(l2))
     want = vt - sigma * (vt / sigma) * ratio[None]
     dual_update_numba(vp, v, lam, sigma=sigma, weight=w)
-    # fp32: the factor 1 - soft/a is a difference of nearly equal numbers where the threshold bites
-    assert (v - want).abs().max().item() < 1e-4 * want.abs().max().item()
+    assert (v - want).abs().max().item() < 1e-11 * want.abs().max().item()
