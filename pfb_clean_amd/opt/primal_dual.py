@@ -62,12 +62,31 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     def host(t):
         return t.cpu().numpy() if as_numpy else t
 
+    # Buffer rotation instead of the reference's end-of-iteration copies `xp = x.copy()`,
+    # `vp = v.copy()` (primal_dual.py:176-177): the freshly written x / v simply become the next
+    # iteration's xp / vp.  For v this is exact only if (a) `psi` overwrites the whole coefficient
+    # support (ours does) and (b) the margins of the packed layout, which psi never writes, are zero
+    # in the caller's v (then they stay zero in both buffers); otherwise the copy is kept.
+    rotate_v = False
+    if getattr(psi, '__self__', None).__class__.__name__ == 'Psi' and getattr(psi, '__name__', '') == 'dot':
+        mark = torch.full_like(vd, float('nan'))
+        psi(xp, mark)
+        rotate_v = not bool(torch.any(vd[torch.isnan(mark)] != 0).item())
+        del mark
+
     eps = 1.0
     numreweight = 0
     k = 0
+    xn, vn = xd, vd                               # where the newest iterate lives
     for k in range(maxit):
-        psi(xp, vd)                                                      # :135
-        dual_update_numba(vp, vd, lam, sigma=sigma, weight=w, vp_out=vp,  # :136-137
+        if k > 0:                                 # :176-177 of the previous iteration
+            xp, xn = xn, xp
+            if rotate_v:
+                vp, vn = vn, vp
+            else:
+                vp.copy_(vn)
+        psi(xp, vn)                                                      # :135
+        dual_update_numba(vp, vn, lam, sigma=sigma, weight=w, vp_out=vp,  # :136-137
                           group=group)
         psiH(vp, xout)                                                   # :138
         g = grad(host(xp))                                               # :139
@@ -76,16 +95,16 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
                                             float(tau),
                                             0 if (group is not None and positivity == 2)
                                             else int(positivity), nband, npix,
-                                            _dev.ptr(xd), _dev.ptr(out), _dev.ptr(ws),
+                                            _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
                                             _dev.stream()))              # :140-146
         if group is not None:
             if positivity == 2:
-                bad = (xd <= 0).any(dim=0).to(torch.uint8)
+                bad = (xn <= 0).any(dim=0).to(torch.uint8)
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=pg)
-                xd.mul_((1 - bad).to(dt)[None])
-                _lib.check(lib.pfb_norm_diff_sums(code, _dev.ptr(xd), _dev.ptr(xp), xd.numel(),
+                xn.mul_((1 - bad).to(dt)[None])
+                _lib.check(lib.pfb_norm_diff_sums(code, _dev.ptr(xn), _dev.ptr(xp), xn.numel(),
                                                   _dev.ptr(out), _dev.ptr(ws), _dev.stream()))
-                out[2] = (xd != 0).any().to(out.dtype)
+                out[2] = (xn != 0).any().to(out.dtype)
             dist.all_reduce(out[:3], op=dist.ReduceOp.SUM, group=pg)
         num, den, anyx = out[:3].tolist()
         if anyx:
@@ -96,14 +115,12 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
             eps = 1.0
         if eps < tol:
             if reweighter is not None and numreweight < maxreweight:
-                w = _dev.to_dev(reweighter(host(xd)), dt).contiguous()
+                w = _dev.to_dev(reweighter(host(xn)), dt).contiguous()
                 numreweight += 1
             else:
                 if numreweight >= maxreweight and verbosity:
                     print("Maximum reweighting steps reached", file=sys.stderr)
                 break
-        xp.copy_(xd)
-        vp.copy_(vd)
         if math.isnan(eps) or math.isinf(eps):
             print("primal_dual: non-finite eps (the reference stops in pdb here)", file=sys.stderr)
             break
@@ -117,11 +134,11 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
             print(f"Success, converged after {k} iterations", file=sys.stderr)
 
     if as_numpy:
-        x[...] = xd.cpu().numpy()
-        v[...] = vd.cpu().numpy()
+        x[...] = xn.cpu().numpy()
+        v[...] = vn.cpu().numpy()
         return x, v
-    if xd is not x:
-        x.copy_(xd)
-    if vd is not v:
-        v.copy_(vd)
+    if xn is not x:
+        x.copy_(xn)
+    if vn is not v:
+        v.copy_(vn)
     return x, v

@@ -243,3 +243,35 @@ def test_primal_dual_device_resident_with_reweighting(amd, golden):
     assert x2 is x and x2.is_cuda
     assert maxerr(x2.cpu().numpy(), xo) < 1e-9 * np.abs(xo).max()
     assert maxerr(v2.cpu().numpy(), vo) < 1e-9 * np.abs(vo).max()
+
+
+def test_primal_dual_nonzero_margins_keep_reference_semantics(amd, golden):
+    """The packed coefficient layout has margins psi never writes.  The reference drags whatever the
+    caller put there through `vtilde = vp + sigma v` and `vp = v.copy()`; the buffer rotation of
+    opt/primal_dual.py is only used when they are zero -- with garbage in the margins the result
+    (margins included) must still equal the oracle's."""
+    g = golden('pd')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx = ny = P // 2
+    bases = [str(s) for s in g['bases']]
+    nbasis = len(bases)
+    data = g['data']
+    rng = np.random.default_rng(77)
+    opsi = owv.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    v0 = rng.standard_normal((nb, nbasis, opsi.Nymax, opsi.Nxmax))
+    x0 = rng.standard_normal((nb, nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, (nb, nx, ny), np.float64)
+    l1w = 0.5 + rng.random((nbasis, opsi.Nymax, opsi.Nxmax))
+    xo, vo = osv.primal_dual_optimised(x0.copy(), v0.copy(), float(g['lam']), opsi.hdot, opsi.dot,
+                                       float(g['hessnorm']), None, l1w,
+                                       None, lambda x: ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x) - data,
+                                       nu=nbasis, tol=0.0, maxit=7, positivity=1)
+    psi = amd.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    conv = partial(amd.psf.psf_convolve_cube, None, None, None, psfhat, Q)
+    x, v = amd.pd.primal_dual_optimised(x0.copy(), v0.copy(), float(g['lam']), psi.hdot, psi.dot,
+                                        float(g['hessnorm']), None, l1w, None,
+                                        lambda t: conv(t) - data, nu=nbasis, tol=0.0, maxit=7,
+                                        positivity=1, verbosity=0)
+    assert maxerr(x, xo) < 1e-9 * np.abs(xo).max()
+    assert maxerr(v, vo) < 1e-9 * np.abs(vo).max()
