@@ -91,6 +91,18 @@ int pfb_psfconv_set_psfhat(pfb_conv_plan* plan, const void* psfhat, void* stream
  * 160 KB (nx_psf <= 10240 fp32 / 5120 fp64); PFB_ERR_UNSUPPORTED beyond that. */
 int pfb_psfconv_set_psf(pfb_conv_plan* plan, const void* psf, void* psfhat_out, void* stream);
 
+/* Re-grid a PSF transform: psfhat on the (nx_psf, ny_psf) grid -> psfhat2 of the SAME image-space
+ * PSF on an (nx_psf2, ny_psf2) grid (both (nband, n, m/2+1) complex, row-major), for images of
+ * (nx, ny) pixels: only the offsets |du| < nx, |dv| < ny a convolution of such an image touches
+ * are carried over (periodically in the old grid, so the wrap-around of grids with
+ * nx_psf < 2 nx is reproduced), which needs nx_psf2 >= 2 nx - 1, ny_psf2 >= 2 ny - 1.
+ * The convolution psf.py:11-56 on the old grid and on the new grid (image zero-padded to
+ * nx_psf2/2 x ny_psf2/2, result cropped) then agree to rounding; the host layer uses this to run
+ * arbitrary image sizes on the power-of-two fast path.  Plan-time, synchronous.  Lines must
+ * fit the LDS (<= 10240 complex64 / 5120 complex128), lengths 13-smooth, last axes even. */
+int pfb_psfhat_regrid(int dtype, const void* psfhat, int nband, int nx, int ny, int nx_psf, int ny_psf,
+                      int nx_psf2, int ny_psf2, void* psfhat2, void* stream);
+
 /* Apply to bands [band0, band0+nb) of the plan.  x, out: (nb, nx, ny) real; out may
  * not alias x.  beam: (nb, nx, ny) or NULL.  wsum <= 0 means "no division"
  * (reference wsum=None).  sigmainv may be 0.

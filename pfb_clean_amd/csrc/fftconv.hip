@@ -180,15 +180,16 @@ k_row_inv_generic(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ tw
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_psfhat_rows(const T* __restrict__ psf, cplx<T>* __restrict__ out, const cplx<T>* __restrict__ twQ,
-              int P, int Q, FftFactors f) {
+              int P, int Q, FftFactors f, int shift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = Q / 2;
     cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
     cplx<T>* bufB = bufA + M;
     const int u = blockIdx.x, band = blockIdx.y;
-    const T* row = psf + ((size_t)band * P + (u + P / 2) % P) * Q;
+    const int su = shift ? P / 2 : 0, sv = shift ? M : 0;                     // Q/2 = M
+    const T* row = psf + ((size_t)band * P + (u + su) % P) * Q;
     for (int n = threadIdx.x; n < M; n += blockDim.x)
-        bufA[n] = cplx<T>(row[(2 * n + M) % Q], row[(2 * n + 1 + M) % Q]);   // Q/2 = M
+        bufA[n] = cplx<T>(row[(2 * n + sv) % Q], row[(2 * n + 1 + sv) % Q]);
     cplx<T>* Z = fft_lds_generic<T, false>(bufA, bufB, f, twQ, 2);
     cplx<T>* orow = out + ((size_t)band * P + u) * (M + 1);
     for (int v = threadIdx.x; v <= M; v += blockDim.x) {
@@ -198,7 +199,7 @@ k_psfhat_rows(const T* __restrict__ psf, cplx<T>* __restrict__ out, const cplx<T
     }
 }
 
-template <typename T>
+template <typename T, bool INV>
 __global__ void __launch_bounds__(256)
 k_psfhat_cols(cplx<T>* __restrict__ out, const cplx<T>* __restrict__ twP, int P, int M1, FftFactors f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -206,8 +207,52 @@ k_psfhat_cols(cplx<T>* __restrict__ out, const cplx<T>* __restrict__ twP, int P,
     cplx<T>* bufB = bufA + P;
     cplx<T>* col = out + (size_t)blockIdx.y * P * M1 + blockIdx.x;
     for (int n = threadIdx.x; n < P; n += blockDim.x) bufA[n] = col[(size_t)n * M1];
-    cplx<T>* X = fft_lds_generic<T, false>(bufA, bufB, f, twP, 1);
+    cplx<T>* X = fft_lds_generic<T, INV>(bufA, bufB, f, twP, 1);
     for (int n = threadIdx.x; n < P; n += blockDim.x) col[(size_t)n * M1] = X[n];
+}
+
+// inverse of k_psfhat_rows (no shift): half spectrum row (M+1 bins, after the inverse column
+// pass) -> Q real samples, unnormalised; DC / Nyquist imaginary parts ignored like ducc's c2r
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_psf_rows_c2r(const cplx<T>* __restrict__ spec, T* __restrict__ psf, const cplx<T>* __restrict__ twQ,
+               int P, int Q, FftFactors f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = Q / 2;
+    cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* bufB = bufA + M;
+    const int u = blockIdx.x, band = blockIdx.y;
+    const cplx<T>* srow = spec + ((size_t)band * P + u) * (M + 1);
+    for (int v = threadIdx.x; v < M; v += blockDim.x) {
+        cplx<T> yv = srow[v], ym = srow[M - v];
+        if (v == 0) { yv.y = 0; ym.y = 0; }
+        ym = conj(ym);
+        bufA[v] = (yv + ym) + mul_i(mulc(yv - ym, twQ[v]));
+    }
+    cplx<T>* z = fft_lds_generic<T, true>(bufA, bufB, f, twQ, 2);
+    T* orow = psf + ((size_t)band * P + u) * Q;
+    for (int n = threadIdx.x; n < M; n += blockDim.x) {
+        orow[2 * n] = z[n].x;
+        orow[2 * n + 1] = z[n].y;
+    }
+}
+
+// psf2[u2][v2] = scale * psf[(du mod P)][(dv mod Q)] for the offsets |du| < nx, |dv| < ny a
+// convolution of an (nx, ny) image can touch (origin at index 0, periodic in the OLD grid --
+// which reproduces the wrap-around of grids with nx_psf < 2 nx exactly), zero elsewhere
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_psf_embed(const T* __restrict__ psf, T* __restrict__ psf2, int nx, int ny, int P, int Q, int P2, int Q2,
+            T scale) {
+    const int v2 = blockIdx.x * blockDim.x + threadIdx.x, u2 = blockIdx.y, band = blockIdx.z;
+    if (v2 >= Q2) return;
+    const int du = u2 < nx ? u2 : u2 - P2, dv = v2 < ny ? v2 : v2 - Q2;
+    T val = 0;
+    if (du > -nx && dv > -ny) {
+        const int u = ((du % P) + P) % P, v = ((dv % Q) + Q) % Q;
+        val = scale * psf[((size_t)band * P + u) * Q + v];
+    }
+    psf2[((size_t)band * P2 + u2) * Q2 + v2] = val;
 }
 
 // out[q] = sum of the n partials of quantity q (q < nq), fixed order => deterministic
@@ -283,7 +328,11 @@ static int set_lds_limits(const pfb_conv_plan*) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_psfhat_rows<T>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_psfhat_cols<T>,
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_psfhat_cols<T, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_psfhat_cols<T, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_psf_rows_c2r<T>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
     return PFB_OK;
 }
@@ -292,11 +341,55 @@ template <typename T>
 static int psfhat_from_psf_t(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st) {
     const size_t lds_r = 2 * sizeof(cplx<T>) * (size_t)p->M, lds_c = 2 * sizeof(cplx<T>) * (size_t)p->P;
     hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(p->P, p->nband), dim3(256), lds_r, st, (const T*)psf,
-                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twQ, p->P, p->Q, p->frow);
-    hipLaunchKernelGGL((k_psfhat_cols<T>), dim3(p->M + 1, p->nband), dim3(256), lds_c, st,
+                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twQ, p->P, p->Q, p->frow, 1);
+    hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(p->M + 1, p->nband), dim3(256), lds_c, st,
                        (cplx<T>*)psfhat_out, (const cplx<T>*)p->twP, p->P, p->M + 1, p->fcol);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
+}
+
+// psfhat on the (P, Q) grid -> psfhat of the SAME image-space PSF on a (P2, Q2) grid, for images
+// of (nx, ny) pixels: inverse transform, embed (k_psf_embed), forward transform.  Lets a plan for
+// an arbitrary size run on the power-of-two fast path (P2 = 2 nx2 >= 2 nx) with identical results.
+template <typename T>
+static int psfhat_regrid_t(const void* psfhat, int nband, int nx, int ny, int P, int Q, int P2, int Q2,
+                           void* psfhat2, hipStream_t st) {
+    const int M = Q / 2, M2 = Q2 / 2;
+    FftFactors fr, fc, fr2, fc2;
+    PFB_REQUIRE(plan_factors(M, &fr) && plan_factors(P, &fc) && plan_factors(M2, &fr2) && plan_factors(P2, &fc2),
+                PFB_ERR_UNSUPPORTED, "psfhat_regrid: a grid length has a prime factor > 13");
+    void *twP = nullptr, *twQ = nullptr, *twP2 = nullptr, *twQ2 = nullptr, *spec = nullptr, *psf = nullptr, *psf2 = nullptr;
+    int rc = upload_twiddles<T>(P, &twP);
+    if (rc == PFB_OK) rc = upload_twiddles<T>(Q, &twQ);
+    if (rc == PFB_OK) rc = upload_twiddles<T>(P2, &twP2);
+    if (rc == PFB_OK) rc = upload_twiddles<T>(Q2, &twQ2);
+    const size_t nspec = (size_t)nband * P * (M + 1), npsf = (size_t)nband * P * Q, npsf2 = (size_t)nband * P2 * Q2;
+    if (rc == PFB_OK && (hipMalloc(&spec, nspec * sizeof(cplx<T>)) != hipSuccess ||
+                         hipMalloc(&psf, npsf * sizeof(T)) != hipSuccess ||
+                         hipMalloc(&psf2, npsf2 * sizeof(T)) != hipSuccess)) {
+        set_error("psfhat_regrid: device allocation failed");
+        rc = PFB_ERR_ALLOC;
+    }
+    if (rc == PFB_OK) {
+        set_lds_limits<T>(nullptr);
+        (void)hipMemcpyAsync(spec, psfhat, nspec * sizeof(cplx<T>), hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL((k_psfhat_cols<T, true>), dim3(M + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P, st,
+                           (cplx<T>*)spec, (const cplx<T>*)twP, P, M + 1, fc);
+        hipLaunchKernelGGL((k_psf_rows_c2r<T>), dim3(P, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M, st,
+                           (const cplx<T>*)spec, (T*)psf, (const cplx<T>*)twQ, P, Q, fr);
+        hipLaunchKernelGGL((k_psf_embed<T>), dim3((Q2 + 255) / 256, P2, nband), dim3(256), 0, st, (const T*)psf,
+                           (T*)psf2, nx, ny, P, Q, P2, Q2, (T)(1.0 / ((double)P * (double)Q)));
+        hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(P2, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M2, st,
+                           (const T*)psf2, (cplx<T>*)psfhat2, (const cplx<T>*)twQ2, P2, Q2, fr2, 0);
+        hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(M2 + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P2,
+                           st, (cplx<T>*)psfhat2, (const cplx<T>*)twP2, P2, M2 + 1, fc2);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            set_error("psfhat_regrid: kernel launch failed");
+            rc = PFB_ERR_HIP;
+        }
+    }
+    for (void* q : {twP, twQ, twP2, twQ2, spec, psf, psf2}) if (q) (void)hipFree(q);
+    return rc;
 }
 
 }  // namespace pfb
@@ -471,6 +564,24 @@ int pfb_psfconv_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, voi
         (void)hipFree(tmp);
     }
     return rc;
+}
+
+int pfb_psfhat_regrid(int dtype, const void* psfhat, int nband, int nx, int ny, int nx_psf, int ny_psf,
+                      int nx_psf2, int ny_psf2, void* psfhat2, void* stream) {
+    PFB_REQUIRE(psfhat && psfhat2 && nband > 0 && nx > 0 && ny > 0, PFB_ERR_INVALID, "psfhat_regrid: bad argument");
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "psfhat_regrid: bad dtype");
+    PFB_REQUIRE(ny_psf % 2 == 0 && ny_psf2 % 2 == 0, PFB_ERR_UNSUPPORTED, "psfhat_regrid: odd last axis");
+    PFB_REQUIRE(nx_psf2 >= 2 * nx - 1 && ny_psf2 >= 2 * ny - 1, PFB_ERR_INVALID,
+                "psfhat_regrid: the new grid (%d,%d) must hold every offset of a (%d,%d) image", nx_psf2, ny_psf2, nx, ny);
+    const size_t csz = dtype == PFB_F32 ? 8 : 16;
+    int big = nx_psf > nx_psf2 ? nx_psf : nx_psf2;
+    if (ny_psf / 2 > big) big = ny_psf / 2;
+    if (ny_psf2 / 2 > big) big = ny_psf2 / 2;
+    PFB_REQUIRE(2 * csz * (size_t)big <= 160 * 1024, PFB_ERR_UNSUPPORTED,
+                "psfhat_regrid: a line of %d complex values does not fit the LDS", big);
+    return dtype == PFB_F32
+        ? psfhat_regrid_t<float>(psfhat, nband, nx, ny, nx_psf, ny_psf, nx_psf2, ny_psf2, psfhat2, as_stream(stream))
+        : psfhat_regrid_t<double>(psfhat, nband, nx, ny, nx_psf, ny_psf, nx_psf2, ny_psf2, psfhat2, as_stream(stream));
 }
 
 static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,

@@ -82,15 +82,17 @@ def _backtrack_mode(backtrack):
 
 
 class _Work:
-    """Device scratch for pfb_pcg_solve, cached per (plan, nb)."""
+    """Device scratch for pfb_pcg_solve, cached per (plan, nb, stream).  id(plan) can be re-used
+    by a NEW plan object of a different size once the old one is garbage collected, so the cached
+    buffer is only handed out if it has exactly the size this plan asks for."""
     _cache = {}
 
     @classmethod
     def get(cls, plan, nb):
         key = (id(plan), nb, _dev.stream())
+        nbytes = _lib.load().pfb_pcg_work_bytes(plan.handle, nb)
         w = cls._cache.get(key)
-        if w is None:
-            nbytes = _lib.load().pfb_pcg_work_bytes(plan.handle, nb)
+        if w is None or w.numel() != nbytes or w.device != plan.device:
             if len(cls._cache) > 4:
                 cls._cache.clear()
             w = cls._cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
@@ -113,6 +115,15 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
     if b3.dtype != plan.rdtype:
         raise TypeError(f"b is {b3.dtype}, operator is {plan.rdtype}")
     x = torch.zeros_like(b3) if x0 is None else (x0[None] if squeeze else x0).contiguous().clone()
+    beam = A.beam
+    if plan.embed is not None:
+        # Embedded plan (arbitrary size on the power-of-two kernels, operators/psf.py): solve in the
+        # zero-padded domain with a beam that is ZERO outside the image.  There A' x' = sigmainv x',
+        # b' = 0 and x0' = 0, so r, y, p stay exactly zero outside and every inner product, step
+        # length and stopping decision equals the un-padded solve's.
+        b3, x = plan._pad(b3, nb), plan._pad(x, nb)
+        beam = plan._pad(torch.ones((nb, plan.nx, plan.ny), dtype=plan.rdtype, device=b3.device)
+                         if beam is None else beam, nb)
     r = torch.empty_like(b3) if return_resid else None
     work = _Work.get(plan, nb)
     res = _lib.PcgResult()
@@ -131,10 +142,13 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
                 return 1
         cb = _lib.ALLREDUCE_FN(_hook)
     _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
-                                 _dev.ptr(A.beam), A.wsum if A.wsum is not None else 0.0,
+                                 _dev.ptr(beam), A.wsum if A.wsum is not None else 0.0,
                                  A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
                                  _backtrack_mode(backtrack), _dev.ptr(work), cb, None, C.byref(res),
                                  _dev.stream()))
+    if plan.embed is not None:
+        x = x[:, :plan.nx, :plan.ny].contiguous()
+        r = None if r is None else r[:, :plan.nx, :plan.ny].contiguous()
     if squeeze:
         x = x[0]
         r = None if r is None else r[0]

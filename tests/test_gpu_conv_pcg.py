@@ -130,7 +130,7 @@ def test_conv_tensor_path_and_fused_dot(amd, shape):
                      dot_with=w, dot_out=dot)
     assert res.data_ptr() == out.data_ptr()
     assert torch.equal(xt, x_keep)
-    assert plan.fast_path == (nx >= 64 and ny >= 128)
+    assert plan.fast_path == (nx >= 64 and ny >= 128) and plan.embed is None
     assert relerr(out.cpu().numpy(), ref) < 1e-12
     assert abs(dot.item() - np.vdot(w.cpu().numpy(), ref)) < 1e-9 * abs(np.vdot(w.cpu().numpy(), ref))
     # sub-range of bands on a multi-band plan
@@ -396,3 +396,55 @@ def test_plan_cache_survives_address_reuse(amd):
         refs.append(ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x).copy())
     for o, r in zip(outs, refs):
         assert relerr(o.cpu().numpy(), r) < 1e-12
+
+
+@pmp('rdt', [np.float64, np.float32])
+@pmp('grid', [(100, 120, 200, 240), (100, 120, 150, 180), (250, 78, 500, 156)])
+def test_embedded_plan_conv_and_pcg(amd, grid, rdt, monkeypatch):
+    """Arbitrary sizes ride the power-of-two kernels through a re-gridded PSF (pfb_psfhat_regrid)
+    and zero-padded images, incl. PSF grids with wrap-around (nx_psf < 2 nx).  The convolution,
+    the Hessian with a beam and the fused PCG must match the oracle on the ORIGINAL grid, and the
+    coverage kernels (PFB_NO_EMBED) on the same inputs."""
+    nx, ny, P, Q = grid
+    rng = np.random.default_rng(nx + P)
+    nb = 2
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    W = rng.poisson(4 * np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2)), size=(nb, P, Q // 2 + 1)).astype(np.float64)
+    W /= nb * np.fft.irfft2(W, s=(P, Q)).max(axis=(1, 2))[:, None, None]
+    psfhat = (W * np.exp(2j * np.pi * rng.random(W.shape) * 0.05)).astype(np.complex128)   # not exactly symmetric
+    psfhat[:, :, 0] = psfhat[:, :, 0].real
+    psfhat[:, :, -1] = psfhat[:, :, -1].real
+    psfhat = ofc.psfhat_from_psf(np.fft.fftshift(np.fft.irfft2(psfhat, s=(P, Q)), axes=(1, 2)))   # a valid real PSF
+    x = rng.standard_normal((nb, nx, ny))
+    beam = 0.5 + rng.random((nb, nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref_c = ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, x).copy()
+    ref_h = ofc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, x, sigmainv=0.3, wsum=1.7)
+    cd = cdt(rdt)
+    tol = TOL_CONV[rdt]
+    amd.psf.clear_plan_cache()
+    plan = amd.psf.plan_for(psfhat.astype(cd), nx, ny, Q)
+    assert plan.embed == (max(64, 1 << (nx - 1).bit_length()), max(128, 1 << (ny - 1).bit_length())) and plan.fast_path
+    got_c = amd.psf.psf_convolve_cube(None, None, None, psfhat.astype(cd), Q, x.astype(rdt))
+    got_h = amd.hessian.hessian_psf_cube(None, None, None, beam.astype(rdt), psfhat.astype(cd), Q, x.astype(rdt),
+                                         sigmainv=0.3, wsum=1.7)
+    assert relerr(got_c, ref_c) < tol and relerr(got_h, ref_h) < tol
+    # fused PCG on the embedded plan == oracle PCG on the original grid
+    sig = 0.05
+    b = ref_c + 0.01 * rng.standard_normal(x.shape)
+
+    def oA(t):
+        return ofc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, t, sigmainv=sig)
+    xo = osv.pcg(oA, b, None, M=lambda t: t / sig, tol=0.0, maxit=8, minit=8)
+    A = partial(amd.hessian.hessian_psf_cube, None, None, None, beam.astype(rdt), psfhat.astype(cd), Q, sigmainv=sig)
+    xg = amd.pcg.pcg(A, b.astype(rdt), None, M=amd.pcg.DivPrecond(sig), tol=0.0, maxit=8, minit=8, verbosity=0)
+    assert relerr(xg, xo) < (1e-9 if rdt == np.float64 else 2e-3)
+    # and the coverage kernels agree
+    monkeypatch.setenv('PFB_NO_EMBED', '1')
+    amd.psf.clear_plan_cache()
+    gen_c = amd.psf.psf_convolve_cube(None, None, None, psfhat.astype(cd), Q, x.astype(rdt))
+    assert amd.psf.plan_for(psfhat.astype(cd), nx, ny, Q).embed is None
+    monkeypatch.delenv('PFB_NO_EMBED')
+    amd.psf.clear_plan_cache()
+    assert relerr(gen_c, got_c) < tol
