@@ -481,9 +481,11 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         // ---- sync-free driver (backtrack off or predictive).  Everything an iteration
         // needs to decide lives in S on the device; the host only has to look when the
         // stopping rule `(eps > tol or k < minit) and k < maxit` can actually fire, i.e.
-        // never while k < minit.  Two all-reduce points per iteration:
-        //   [p.Ap, r.Ap, Ap.Ap, any(p)]  and  [r'.y', |x'-x|^2, |x'|^2].
+        // never while k < minit.  Two reduction points per iteration:
+        //   [p.Ap, r.Ap, Ap.Ap, any(p)]  and  [r'.y', |x'-x|^2, |x'|^2]
+        // -- with sharded bands one all-reduce each, merged into ONE per iteration while k < minit.
         int khost = 0;
+        bool pending_end = false;
         bool go = (1.0 > tol || 0 < minit) && 0 < maxit;
         const char* nf = getenv("PFB_PCG_NO_FUSE_DIR");
         const bool fuse_dir = !(nf && atoi(nf));     // A/B switch: separate update / direction kernels
@@ -493,7 +495,14 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
             else
                 err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
             if (err != PFB_OK) return err;
-            if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
+            if (pending_end) {
+                // the previous iteration left [r'.y', |x'-x|^2, |x'|^2] un-reduced: they sit right
+                // behind [p.Ap, r.Ap, Ap.Ap, any(p)] in S, so ONE all-reduce of 7 scalars serves
+                // both reduction points (sharded bands: one RCCL call per iteration instead of two)
+                if ((err = reduce_hook(S_PAP, 7)) != PFB_OK) return err;
+                hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                pending_end = false;
+            } else if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
             if (fuse_dir) {
                 // needs <r,Ap>, <Ap,Ap> even without backtracking (beta comes from rho(alpha))
                 hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
@@ -502,8 +511,14 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
                                (const double*)(S + S_ALPHA), mdiv);
                 hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
                 hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws + 3 * (size_t)G_used, G_used, 1, S + S_ANY);
-                if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
-                hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                // nobody looks at k / eps before the next iteration while k < minit: fold this
+                // reduction point into the next iteration's (only worth it with a real all-reduce)
+                if (allreduce && khost + 1 < minit && khost + 1 < maxit) {
+                    pending_end = true;
+                } else {
+                    if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
+                    hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                }
                 { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
             } else {
                 hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 1 : 0);

@@ -345,3 +345,70 @@ def test_psfhat_producer_falls_back_for_odd_last_axis():
     from pfb_clean_amd.operators.fft import psfhat_from_psf
     psf = np.random.default_rng(2).standard_normal((1, 30, 33))
     assert np.abs(psfhat_from_psf(psf) - ofc.psfhat_from_psf(psf)).max() < 1e-11
+
+
+def _pcg_rank(rank, world, port, q):
+    """One rank of the band-sharded cube PCG through pfb_pcg_solve + AllReduceHook (gloo group, two
+    processes on the single test GPU; uneven shard 2 + 1 bands of the golden cube)."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from pfb_clean_amd.dist import shard_bands
+        from pfb_clean_amd.operators.hessian import HessianPsf
+        from pfb_clean_amd.opt.pcg import pcg_fused
+        here = os.path.dirname(os.path.abspath(__file__))
+        g = np.load(os.path.join(here, 'golden', 'pcg.npz'))
+        psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+        sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+        nband, nx, ny = b.shape
+        band0, nb = shard_bands(nband, rank, world)
+        sl = slice(band0, band0 + nb)
+        dev = torch.device('cuda')
+        A = HessianPsf(torch.from_numpy(psfhat[sl]).to(dev), nx, ny, Q, beam=torch.from_numpy(beam[sl]).to(dev),
+                       sigmainv=sigmainv, wsum=1.0)
+        bt = torch.from_numpy((beam * b)[sl]).to(dev)
+        res = {}
+        for tag, kw in (('fixed', dict(tol=0.0, maxit=10, minit=10)), ('stop', dict(tol=2e-2, maxit=60, minit=3))):
+            x, _, r = pcg_fused(A, bt, None, mdiv=sigmainv, distributed=True, **kw)
+            res[tag] = (x.cpu().numpy(), r.iters)
+        q.put((rank, band0, nb, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_band_sharded_cube_pcg_two_ranks_one_gpu():
+    """cube PCG with the bands split over two ranks equals the oracle's single-process
+    solve -- once with k < minit throughout (ONE merged all-reduce per iteration) and once with the
+    stopping rule live after minit (two reduction points, host looks every iteration)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pcg.npz'))
+    psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, np.float64)
+
+    def oA(v):
+        return ofc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, v, sigmainv=sigmainv, wsum=1.0)
+    ref = {}
+    for tag, kw in (('fixed', dict(tol=0.0, maxit=10, minit=10)), ('stop', dict(tol=2e-2, maxit=60, minit=3))):
+        tr = osv.PCGTrace()
+        ref[tag] = (osv.pcg(oA, beam * b, None, M=lambda v: v / sigmainv, trace=tr, **kw), len(tr.eps))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pcg_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, band0, nb, res in out:
+        for tag in ('fixed', 'stop'):
+            x, iters = res[tag]
+            xr, kref = ref[tag]
+            assert iters == kref, (tag, iters, kref)
+            assert np.abs(x - xr[band0:band0 + nb]).max() < 1e-9 * np.abs(xr).max(), (rank, tag)
