@@ -88,6 +88,19 @@ k_final_sum(const double* __restrict__ ws, int G, int nq, double* __restrict__ o
     }
 }
 
+// the fused update's four sums in one launch: wave q sums quantity q (fixed order ->
+// deterministic) and writes out[dst[q]] -- [r'.y', |x'-x|^2, |x'|^2] go to S_RHON.., count(p') to S_ANY
+struct Dst4 { int d[4]; };
+__global__ void __launch_bounds__(256)
+k_final_sum_waves(const double* __restrict__ ws, int G, int nq, double* __restrict__ out, Dst4 dst) {
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    double acc = 0.0;
+    for (int g = lane; g < G; g += 64) acc += ws[(size_t)q * G + g];
+    acc = wave_sum(acc);
+    if (lane == 0) out[dst.d[q]] = acc;
+}
+
 template <typename T, int V>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_dot(const T* __restrict__ a, const T* __restrict__ b, size_t nvec, double* __restrict__ ws) {
@@ -509,8 +522,8 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
                 PFB_LAUNCH_VEC(T, k_pcg_update_dir, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
                                (const T*)rcur, p, (const T*)Ap, xnew, rnew,
                                (const double*)(S + S_ALPHA), mdiv);
-                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 3, S + S_RHON);
-                hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws + 3 * (size_t)G_used, G_used, 1, S + S_ANY);
+                hipLaunchKernelGGL(k_final_sum_waves, dim3(1), dim3(256), 0, st, ws, G_used, 4, S,
+                                   (Dst4{{S_RHON, S_NUM, S_DEN, S_ANY}}));
                 // nobody looks at k / eps before the next iteration while k < minit: fold this
                 // reduction point into the next iteration's (only worth it with a real all-reduce)
                 if (allreduce && khost + 1 < minit && khost + 1 < maxit) {
