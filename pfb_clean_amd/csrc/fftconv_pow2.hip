@@ -73,6 +73,12 @@ template <typename T, int L> struct InvDb {
 
 constexpr int LDS_BUDGET = 152 * 1024;
 
+// elements per thread of the column transform: 8, but 16 for fp64 at H = 8192 -- with E = 8 that
+// size needs a 1024-thread workgroup (128-VGPR cap) and spilled ~200 bytes per lane: 4.32 -> 3.29 ms
+// per 2 bands.  (fp32 at 8192 is the other way round: E = 16 under its 4-waves/SIMD launch bound
+// spills 788 bytes, 2.22 -> 3.58 ms.)
+template <typename T, int H> constexpr int ecol() { return (H >= 8192 && sizeof(T) == 8) ? 16 : FastCfg<T>::ECOL; }
+
 // rows per workgroup for the row kernels
 template <typename T, int L, int E, int GMAX>
 constexpr int row_groups() {
@@ -684,12 +690,17 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     const V2* dr2 = dot_with2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) + t : nullptr;
     V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
     const bool dot_is_x = dot_with == x;            // PCG: <p, A p> with x = p
-    V2 xq[E], rq[E];
+    // fp64: 2 x 32 more registers for the prefetched operands do not exist under the 128-VGPR cap of
+    // a 1024-thread workgroup (it spilled 80-94 registers); they are read in the epilogue instead
+    constexpr bool PREF = sizeof(T) == 4 || NT < 1024;
+    V2 xq[PREF ? E : 1], rq[PREF ? E : 1];
     row_inv_phase<T, L, E, 1>([&] {
+        if constexpr (PREF) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            xq[j] = xr[TPB * j];
-            if (dr2) rq[j] = dr2[TPB * j];
+            for (int j = 0; j < E; ++j) {
+                xq[j] = xr[TPB * j];
+                if (dr2) rq[j] = dr2[TPB * j];
+            }
         }
     }, Tb, twQ, ltw, lds0, lds, d.nx, i0, t, vv);
     // z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
@@ -702,7 +713,8 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
         val.x = zz.x * scale;
         val.y = zz.y * scale;
         if (br) { const V2 b = br[TPB * j]; val.x *= b.x; val.y *= b.y; }
-        const V2 xx = xq[j];
+        V2 xx;
+        if constexpr (PREF) xx = xq[j]; else xx = xr[TPB * j];
         val.x += sigmainv * xx.x;
         val.y += sigmainv * xx.y;
         orow[TPB * j] = val;
@@ -711,7 +723,8 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
             if (!dot_is_x) dw = dr[TPB * j];
             acc[0] += (double)dw.x * (double)val.x + (double)dw.y * (double)val.y;
             if (dr2) {
-                const V2 d2 = rq[j];
+                V2 d2;
+                if constexpr (PREF) d2 = rq[j]; else d2 = dr2[TPB * j];
                 acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
             }
             acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
@@ -993,11 +1006,11 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     int rc = PFB_ERR_UNSUPPORTED;
     constexpr int lds_max = 160 * 1024;
     switch (H) {
-#define X(NN) case NN: rc = prep_ptw<T, NN, FastCfg<T>::ECOL>(&ft->ptw_col);                          \
-        if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, FastCfg<T>::ECOL>(&ft->ptwc_col);             \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2<T, NN, FastCfg<T>::ECOL>, \
+#define X(NN) case NN: rc = prep_ptw<T, NN, ecol<T, NN>()>(&ft->ptw_col);                          \
+        if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, ecol<T, NN>()>(&ft->ptwc_col);             \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2<T, NN, ecol<T, NN>()>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_col_pow2p<T, NN, FastCfg<T>::ECOL>, \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>()>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -1111,7 +1124,7 @@ int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st) {
 
 template <typename T, int H>
 static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st) {
-    constexpr int E = FastCfg<T>::ECOL;
+    constexpr int E = ecol<T, H>();
     using F = RegFft<T, H, E>;
     constexpr int GC = col_groups<H, E>();
     const int nblk = fast_nblocks(p->ny / 2, FastCfg<T>::NVB);
