@@ -76,7 +76,7 @@ constexpr int LDS_BUDGET = 152 * 1024;
 // elements per thread of the column transform: 8, but 16 for fp64 at H = 8192 -- with E = 8 that
 // size needs a 1024-thread workgroup (128-VGPR cap) and spilled ~200 bytes per lane: 4.32 -> 3.29 ms
 // per 2 bands.  (fp32 at 8192 is the other way round: E = 16 under its 4-waves/SIMD launch bound
-// spills 788 bytes, 2.22 -> 3.58 ms.)
+// spills 788 bytes, 2.22 -> 3.58 ms, and still 2.66 ms with a 2-waves/SIMD bound and 84 bytes.)
 template <typename T, int H> constexpr int ecol() { return (H >= 8192 && sizeof(T) == 8) ? 16 : FastCfg<T>::ECOL; }
 
 // rows per workgroup for the row kernels
@@ -153,7 +153,7 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
 
 // ------------------------------------------------------------------------ column
 template <typename T, int H, int E>
-__global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), FastCfg<T>::WCOL)
+__global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), (E >= 16 ? 2 : FastCfg<T>::WCOL))
 k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
            int nblk, size_t T_band, size_t psf_band, int band0) {
