@@ -233,7 +233,10 @@ def cpu_baseline(psfhat_dev, b_dev, sigmainv, n, nband, seconds, x_gpu):
     """Oracle (numpy + scipy.fft, all host cores) on ONE band of the cube: per-band PCG is
     the same arithmetic per band as the cube PCG; cube-matvecs/s = band rate / nband."""
     from oracle import fftconv as ofc, solvers as osv
-    cores = os.cpu_count() or 1
+    # scipy.fft gets SLOWER beyond ~16 workers at this size (tools/cpu_workers_sweep.py on the GPU box:
+    # 209 ms per 4096^2 band-matvec with 16 workers, 300 ms with 64, 640 ms with 256), and 16 is
+    # also the CPU share of a one-GPU box: use 16 threads and report them
+    cores = min(16, os.cpu_count() or 1)
     psfhat = psfhat_dev.cpu().numpy()
     b = b_dev.cpu().numpy()
     Q = 2 * n
@@ -256,7 +259,8 @@ def cpu_baseline(psfhat_dev, b_dev, sigmainv, n, nband, seconds, x_gpu):
             "kind": "port",
             "sample": f"oracle pcg (numpy + scipy.fft {scipy.__version__} workers={cores}) on 1 of "
                       f"{nband} bands, {iters} iterations = {iters + 1} matvecs in {dt:.1f} s; "
-                      f"cube rate = band rate / {nband}",
+                      f"cube rate = band rate / {nband}; host has {os.cpu_count()} cores, "
+                      f"scipy.fft is fastest at ~16 workers for this size",
             "band_matvecs_per_s": round(band_rate, 3)}
 
 
