@@ -19,9 +19,11 @@
  *     except functions documented to (the *_solve drivers read scalars back);
  *   - the library never allocates caller-visible memory: plans own their twiddles /
  *     re-laid-out PSF / workspaces, callers own every vector;
- *   - one plan may be used by one stream at a time; distinct plans are independent
- *     and there is no global mutable state (re-entrant like the reference, which
- *     dask may call from several threads, pcg.py:346-356).
+ *   - one plan may be used by one stream AND one host thread at a time (its spectrum
+ *     workspace, fused-dot partials and profiling slots are per plan); distinct plans
+ *     are independent and there is no global mutable state (re-entrant like the
+ *     reference, which dask may call from several threads with one band each,
+ *     pcg.py:346-356 -- one plan per band there).
  */
 #ifndef PFB_HIP_H
 #define PFB_HIP_H

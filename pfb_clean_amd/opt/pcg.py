@@ -24,6 +24,7 @@ import functools
 import math
 import os
 import sys
+import threading
 
 import numpy as np
 import torch
@@ -89,11 +90,13 @@ class _Work:
 
     @classmethod
     def get(cls, plan, nb):
-        key = (id(plan), nb, _dev.stream())
+        # per host thread: the reference may drive per-band solves from several dask threads
+        # (pcg.py:346-356); solves on different band ranges of one plan must not share scratch
+        key = (id(plan), nb, _dev.stream(), threading.get_ident())
         nbytes = _lib.load().pfb_pcg_work_bytes(plan.handle, nb)
         w = cls._cache.get(key)
         if w is None or w.numel() != nbytes or w.device != plan.device:
-            if len(cls._cache) > 4:
+            if len(cls._cache) > 16:
                 cls._cache.clear()
             w = cls._cache[key] = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
         return w

@@ -448,3 +448,35 @@ def test_embedded_plan_conv_and_pcg(amd, grid, rdt, monkeypatch):
     monkeypatch.delenv('PFB_NO_EMBED')
     amd.psf.clear_plan_cache()
     assert relerr(gen_c, got_c) < tol
+
+
+def test_per_band_solves_from_concurrent_host_threads(amd, golden):
+    """The reference's dask `threads` scheduler runs _pcg_psf for different bands concurrently
+    (pcg.py:346-356).  Here: one host thread per band, each with its own per-band plan (what
+    functools.partial(_hessian_psf_slice, psfhat[k], ...) gives), all on the same stream -- the
+    results must equal the sequential ones bitwise."""
+    import threading
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nband = b.shape[0]
+    dev = torch.device('cuda')
+    ops = [amd.hessian.HessianPsf(torch.from_numpy(psfhat[k]).to(dev), b.shape[1], b.shape[2], Q,
+                                  beam=torch.from_numpy(beam[k]).to(dev), sigmainv=sigmainv) for k in range(nband)]
+    rhs = [torch.from_numpy((beam * b)[k]).to(dev) for k in range(nband)]
+
+    def solve(k):
+        return amd.pcg.pcg_fused(ops[k], rhs[k], None, mdiv=sigmainv, tol=0.0, maxit=12, minit=12)[0]
+    seq = [solve(k).clone() for k in range(nband)]
+    for _ in range(3):
+        out = [None] * nband
+
+        def work(k):
+            out[k] = solve(k)
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(nband)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k in range(nband):
+            assert torch.equal(out[k], seq[k]), k
