@@ -106,22 +106,57 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
 #pragma unroll
     for (int j = 0; j < F; ++j) { lo[j] = f.lo[j]; hi[j] = f.hi[j]; }
     // 1. stage the input tile (zero extension outside the signal)
-    constexpr int NLD = (NI * NI + 255) / 256;
-    T stage[NLD];
+    constexpr int VW = 16 / (int)sizeof(T);                      // elements per 16-byte access
+    if (ldin % VW == 0 && nyin % VW == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // rows are 16-byte aligned (the finest level of an image whose width is a multiple of 4):
+        // aligned 16-byte loads of a slightly wider window -- 4x fewer load instructions, and every
+        // vector lies entirely inside or entirely outside [0, nyin)
+        struct alignas(16) Vec { T e[VW]; };
+        const int ga = gy0 - (((gy0 % VW) + VW) % VW);           // window start, rounded down
+        constexpr int NWV = (NI + 2 * (VW - 1) + VW - 1) / VW;   // vectors per tile row (upper bound)
+        constexpr int NLV = (NI * NWV + 255) / 256;
+        Vec stage[NLV];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int lx = e / NI, ly = e - lx * NI;
-        const int gx = gx0 + lx, gy = gy0 + ly;
-        T v = 0;
-        if (e < NI * NI && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
-        stage[k] = v;
-    }
+        for (int k = 0; k < NLV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NWV, w = e - lx * NWV;
+            const int gx = gx0 + lx, gy = ga + VW * w;
+            Vec v;
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int lx = e / NI, ly = e - lx * NI;
-        if (e < NI * NI) A[lx * SA + ly] = stage[k];
+            for (int c = 0; c < VW; ++c) v.e[c] = 0;
+            if (e < NI * NWV && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin)
+                v = *reinterpret_cast<const Vec*>(src + (size_t)gx * ldin + gy);
+            stage[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NLV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NWV, w = e - lx * NWV;
+            const int ly0 = ga - gy0 + VW * w;
+            if (e < NI * NWV) {
+#pragma unroll
+                for (int c = 0; c < VW; ++c)
+                    if (ly0 + c >= 0 && ly0 + c < NI) A[lx * SA + ly0 + c] = stage[k].e[c];
+            }
+        }
+    } else {
+        constexpr int NLD = (NI * NI + 255) / 256;
+        T stage[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NI, ly = e - lx * NI;
+            const int gx = gx0 + lx, gy = gy0 + ly;
+            T v = 0;
+            if (e < NI * NI && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
+            stage[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NI, ly = e - lx * NI;
+            if (e < NI * NI) A[lx * SA + ly] = stage[k];
+        }
     }
     __syncthreads();
     // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
