@@ -216,7 +216,7 @@ struct RegFft {
     }
     static constexpr int TPB = N / E;
     static constexpr int RM = rmax_of(E);
-    static constexpr int LDS_ELEMS = N + N / (RM < 16 ? RM : 16);   // room for every padding below
+    static constexpr int LDS_ELEMS = N + N / (RM < (128 / (int)sizeof(cplx<T>)) ? RM : (128 / (int)sizeof(cplx<T>)));   // room for every padding below
     static constexpr int PTW = ptw_total<N, E>();
     static constexpr int PTWC = ptw_total<N, E>() / 4;          // compact (w only) table size
 
@@ -227,21 +227,24 @@ struct RegFft {
     static constexpr int cpad(int c) { return c + (c >> 4); }
 
     // Padding of the EXCHANGE after the pass with predecessor product P (radix R), chosen per
-    // pass so that the scattered writes are bank-conflict free (the reads are contiguous):
-    //   P = 1   lane i writes element i*R (+s): stride-R -> one extra element per 256 bytes
-    //           of lanes (fp32: c + c/32, fp64: c + c/16)
+    // pass so that the scattered writes are bank-conflict free (the reads are contiguous).
+    // The LDS behaves as 32 banks x 4 bytes = 128 bytes per clock (SQ_LDS_BANK_CONFLICT on
+    // stride-2 fp32 reads: exactly 50 %), i.e. SLOTS = 16 complex64 / 8 complex128 elements
+    // served per clock, taken by SLOTS consecutive lanes:
+    //   P = 1   lane i writes element i*R (+s): the SLOTS lanes of a group would share 2 (1)
+    //           slots -> shift by one element per SLOTS elements: c + c/SLOTS
     //   P > 1   P consecutive lanes write P contiguous elements, the next P lanes start P*R
-    //           further: shift every P*R block by P elements; nothing needed once P lanes
-    //           alone cover the 64 banks (P >= 32 fp32 / 16 fp64).
-    // (the uniform i + i/16 gave 2-way conflicts on the P = 1 and P = 8 writes: ~35 % of all
-    // LDS cycles of the column kernel, SQ_LDS_BANK_CONFLICT / SQ_LDS_ACTIVE)
+    //           further (a multiple of SLOTS): shift every P*R block by P elements; nothing
+    //           needed once P lanes alone fill a clock (P >= SLOTS).
+    // (measured on the column kernel: uniform i + i/16 everywhere 35 % of the LDS cycles in
+    // conflicts; P-dependent shifts as below but c/32 for P = 1: 15 %)
     // As for pad/cpad above: xpad(b + c) == xpad(b) + cxpad(c) for every (base, constant) used.
     static constexpr int CB = (int)sizeof(cplx<T>);
-    static constexpr int WLANES = 256 / CB;
+    static constexpr int SLOTS = 128 / CB;
     template <int P, int R>
     static constexpr int cxpad(int c) {
-        if (P == 1) return c + (c >> (CB == 8 ? 5 : 4));
-        if (P >= WLANES) return c;
+        if (P == 1) return c + c / SLOTS;
+        if (P >= SLOTS) return c;
         return c + (c / (P * R)) * P;
     }
     template <int P, int R>
