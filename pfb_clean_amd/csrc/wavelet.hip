@@ -50,6 +50,12 @@ struct pfb_psi_plan {
     pfb::BasisInfo* bases;
     void* scratch[2];           // per band ping-pong approx / partial-image buffers
     size_t scratch_band;        // elements per band in each scratch buffer
+    // fused finest synthesis level (k_idwt_finest_fused): per-basis parameter table on the device
+    // and one level-1 partial image per basis and band (all alive when the fused kernel runs)
+    void* fin_prm;
+    void* fin_scratch;
+    size_t fin_band, fin_basis;
+    int fin_fmax;
 };
 
 namespace pfb {
@@ -441,6 +447,170 @@ k_final_sum3(const double* __restrict__ ws, int G, int nq, double* __restrict__ 
 }
 
 // ------------------------------------------------------------------- host drivers
+// ---------------------------------------------------- fused finest synthesis level
+// psi.hdot sums the bases: x = sum_b idwt_b(alpha_b).  Run basis by basis, the finest level
+// read-modify-writes the image once per basis (5 bases: 0.67 GB of the ~1 GB the whole hdot
+// moves at 2048^2 x 4).  Here ONE kernel walks all bases for its image tile, accumulates the
+// finest-level results in registers and stores the image once.
+template <typename T> struct FinBasis {
+    long long coeff_off;        // level-0 block origin inside a band's coefficient planes
+    long long prev_off;         // this basis' level-1 partial image inside fin_scratch (per band 0)
+    int K, F, nax, nay, has_prev, ldp;
+    T lo[MAXF], hi[MAXF];       // rec_lo, rec_hi
+};
+
+// one basis' contribution to the thread's output pairs (same staging / passes as k_idwt_level)
+template <typename T, int F, int TS>
+__device__ __forceinline__ void idwt_tile_acc(T* smem, const FinBasis<T>& B, const T* __restrict__ src, int ldc,
+                                              const T* __restrict__ pv, int ix0, int iy0, int tid,
+                                              T (&acc)[TS * (TS / 2) / 256][2]) {
+    constexpr int h = F / 2;
+    constexpr int NC = TS / 2 + h - 1;
+    constexpr int SC = 2 * NC + 1;
+    constexpr int ST = TS + 1;
+    T* C = smem;
+    T* Tm = C + 2 * NC * SC;
+    const int nax = B.nax, nay = B.nay, ldp = B.ldp;
+    const int mx0 = ix0 / 2, my0 = iy0 / 2;
+    T lo[F], hi[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { lo[j] = B.lo[j]; hi[j] = B.hi[j]; }
+    constexpr int NE = 4 * NC * NC;
+    constexpr int NLD = (NE + 255) / 256;
+    T stage[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = tid + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+        const bool hy = ry >= NC, hx = cx >= NC;
+        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
+        T v = 0;
+        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
+            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+        stage[k] = v;
+    }
+    constexpr int NLP = (NC * NC + 255) / 256;
+    T stagep[NLP];
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = tid + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;
+            const int gy = my0 + ry, gx = mx0 + cx;
+            T v = 0;
+            if (e < NC * NC && gy < nay && gx < nax) v = pv[(size_t)gx * ldp + gy];
+            stagep[k] = v;
+        }
+    }
+    __syncthreads();                                   // the previous basis is done with the LDS
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = tid + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
+    }
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = tid + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;
+            if (e < NC * NC) C[ry * SC + cx] = stagep[k];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * NC * (TS / 2); e += 256) {
+        const int ry = e / (TS / 2), m = e - ry * (TS / 2);
+        const T* c = C + ry * SC + m + h - 1;
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = c[-j], d = c[NC - j];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        Tm[ry * ST + 2 * m] = sl0 + sh0;
+        Tm[ry * ST + 2 * m + 1] = sl1 + sh1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TS * (TS / 2) / 256; ++k) {
+        const int e = tid + 256 * k;
+        const int ox = e / (TS / 2), m = e - ox * (TS / 2);
+        const T* t = Tm + (m + h - 1) * ST + ox;
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = t[-j * ST], d = t[(NC - j) * ST];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        acc[k][0] += sl0 + sh0;
+        acc[k][1] += sl1 + sh1;
+    }
+}
+
+template <typename T, int TS, int FMAX>
+__global__ void __launch_bounds__(256)
+k_idwt_finest_fused(const T* __restrict__ alpha, size_t aband, int ldc, const FinBasis<T>* __restrict__ prm,
+                    int nbasis, const T* __restrict__ fin, size_t fin_band,
+                    T* __restrict__ xo, size_t xband, int ldo, int nxw, int nyw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    constexpr int NP = TS * (TS / 2) / 256;
+    T acc[NP][2];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { acc[k][0] = 0; acc[k][1] = 0; }
+    const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
+    const T* ab = alpha + (size_t)blockIdx.z * aband;
+    for (int ib = 0; ib < nbasis; ++ib) {
+        const FinBasis<T>& B = prm[ib];
+        const T* src = ab + B.coeff_off;
+        // the per-thread index arithmetic of every basis body is loop invariant: without this the
+        // compiler hoists all of it out of the basis loop (256 VGPRs, occupancy 2; with it 8x less)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (B.K == 0) {
+            // 'self': x[gx][gy] += alpha[gy][gx]  (psi.py:229-232) through an LDS transpose
+            constexpr int SS = TS + 1;
+            __syncthreads();
+            for (int e = tid; e < TS * TS; e += 256) {
+                const int ly = e / TS, lx = e - ly * TS;                  // lx fastest: rows of alpha
+                T v = 0;
+                if (iy0 + ly < nyw && ix0 + lx < nxw) v = src[(size_t)(iy0 + ly) * ldc + ix0 + lx];
+                smem[ly * SS + lx] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int e = tid + 256 * k;
+                const int ox = e / (TS / 2), m = e - ox * (TS / 2);
+                acc[k][0] += smem[(2 * m) * SS + ox];
+                acc[k][1] += smem[(2 * m + 1) * SS + ox];
+            }
+            continue;
+        }
+        const T* pv = B.has_prev ? fin + B.prev_off + (size_t)blockIdx.z * fin_band : nullptr;
+        switch (B.F) {
+#define X(FF) case FF: if constexpr (FF <= FMAX) idwt_tile_acc<T, FF, TS>(smem, B, src, ldc, pv, ix0, iy0, tid, acc); break;
+            X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+            default: break;
+        }
+    }
+    T* dst = xo + (size_t)blockIdx.z * xband;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ox = e / (TS / 2), m = e - ox * (TS / 2);
+        const int gx = ix0 + ox, gy = iy0 + 2 * m;
+        if (gx < nxw) {
+            T* q = dst + (size_t)gx * ldo + gy;
+            if (gy < nyw) q[0] = acc[k][0];
+            if (gy + 1 < nyw) q[1] = acc[k][1];
+        }
+    }
+}
+
 template <typename T>
 static Filt<T> make_filt(const BasisInfo& b, int lo_idx, int hi_idx) {
     Filt<T> f;
@@ -538,7 +708,101 @@ static int psi_dot_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st) {
 }
 
 template <typename T>
+static int psi_fin_prepare(pfb_psi_plan* p) {
+    // parameter table + per-basis level-1 partial images of the fused finest level (once per plan)
+    if (p->fin_prm) return PFB_OK;
+    const size_t plane = (size_t)p->Nymax * p->Nxmax;
+    std::vector<FinBasis<T>> h(p->nbasis);
+    size_t fin_band = 1;
+    int fmax = 2;
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        const BasisInfo& b = p->bases[ib];
+        if (b.K != 0 && p->nlevel > 1) {
+            const size_t e = (size_t)b.lev[1].nxo * b.lev[1].nyo;
+            if (e > fin_band) fin_band = e;
+        }
+        if (b.K != 0 && b.F > fmax) fmax = b.F;
+    }
+    p->fin_band = fin_band;
+    p->fin_basis = fin_band * p->nband;
+    p->fin_fmax = fmax;
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        const BasisInfo& b = p->bases[ib];
+        FinBasis<T>& q = h[ib];
+        memset(&q, 0, sizeof(q));
+        q.K = b.K;
+        q.F = b.F;
+        if (b.K == 0) { q.coeff_off = (long long)((size_t)ib * plane); continue; }
+        const LevelInfo& L = b.lev[0];
+        q.coeff_off = (long long)((size_t)ib * plane + (size_t)L.lowy * p->Nxmax + L.lowx);
+        q.nax = L.Cx; q.nay = L.Cy;
+        q.has_prev = p->nlevel > 1;
+        q.ldp = p->nlevel > 1 ? b.lev[1].nyo : 0;
+        q.prev_off = (long long)((size_t)ib * p->fin_basis);
+        for (int k = 0; k < b.F; ++k) { q.lo[k] = (T)b.filt[2][k]; q.hi[k] = (T)b.filt[3][k]; }
+    }
+    PFB_HIP_CHECK(hipMalloc(&p->fin_prm, sizeof(FinBasis<T>) * h.size()));
+    PFB_HIP_CHECK(hipMemcpy(p->fin_prm, h.data(), sizeof(FinBasis<T>) * h.size(), hipMemcpyHostToDevice));
+    PFB_HIP_CHECK(hipMalloc(&p->fin_scratch, sizeof(T) * p->fin_basis * p->nbasis));
+    constexpr int TS = Tile<T>::TS;
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PFB_OK;
+}
+
+// all bases' finest level in one kernel (image written once); coarser levels basis by basis
+template <typename T>
+static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
+    int rc = psi_fin_prepare<T>(p);
+    if (rc != PFB_OK) return rc;
+    const size_t plane = (size_t)p->Nymax * p->Nxmax;
+    const size_t aband = plane * p->nbasis;
+    const size_t xband = (size_t)p->nx * p->ny;
+    constexpr int TS = Tile<T>::TS;
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        const BasisInfo& b = p->bases[ib];
+        if (b.K == 0 || p->nlevel < 2) continue;
+        const Filt<T> f = make_filt<T>(b, 2, 3);
+        const T* ab = alpha + (size_t)ib * plane;
+        const T* prev = nullptr;
+        int ldp = 0;
+        for (int l = p->nlevel - 1; l >= 1; --l) {
+            const LevelInfo& L = b.lev[l];
+            const T* blk = ab + (size_t)L.lowy * p->Nxmax + L.lowx;
+            T* out = l == 1 ? (T*)p->fin_scratch + (size_t)ib * p->fin_basis : (T*)p->scratch[l & 1];
+            const size_t o_band = l == 1 ? p->fin_band : p->scratch_band;
+            dim3 grid((L.nxo + TS - 1) / TS, (L.nyo + TS - 1) / TS, p->nband);
+            launch_idwt<T, false>(b.F, grid, idwt_lds<T>(b.F), st, blk, aband, p->Nxmax, L.Cx, L.Cy, prev,
+                                  p->scratch_band, ldp, out, o_band, L.nyo, L.nxo, L.nyo, f);
+            prev = out;
+            ldp = L.nyo;
+        }
+    }
+    dim3 grid((p->nx + TS - 1) / TS, (p->ny + TS - 1) / TS, p->nband);
+    size_t lds = idwt_lds<T>(p->fin_fmax);
+    const size_t lds_self = sizeof(T) * (size_t)TS * (TS + 1);
+    if (lds < lds_self) lds = lds_self;
+    if (p->fin_fmax <= 8)
+        hipLaunchKernelGGL((k_idwt_finest_fused<T, TS, 8>), grid, dim3(256), lds, st, alpha, aband, p->Nxmax,
+                           (const FinBasis<T>*)p->fin_prm, p->nbasis, (const T*)p->fin_scratch, p->fin_band,
+                           xo, xband, p->ny, p->nx, p->ny);
+    else
+        hipLaunchKernelGGL((k_idwt_finest_fused<T, TS, 18>), grid, dim3(256), lds, st, alpha, aband, p->Nxmax,
+                           (const FinBasis<T>*)p->fin_prm, p->nbasis, (const T*)p->fin_scratch, p->fin_band,
+                           xo, xband, p->ny, p->nx, p->ny);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+template <typename T>
 static int psi_hdot_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
+    {
+        static int fused = -1;
+        if (fused < 0) { fused = 1; if (const char* e = getenv("PFB_PSI_FUSED")) fused = atoi(e) ? 1 : 0; }
+        if (fused && p->nbasis > 0) return psi_hdot_fused_t<T>(p, alpha, xo, st);
+    }
     const size_t plane = (size_t)p->Nymax * p->Nxmax;
     const size_t aband = plane * p->nbasis;
     const size_t xband = (size_t)p->nx * p->ny;
@@ -688,6 +952,8 @@ int pfb_psi_plan_create(int nband, int nx, int ny, int nbasis, const int* basis_
 int pfb_psi_plan_destroy(pfb_psi_plan* p) {
     if (!p) return PFB_OK;
     for (int k = 0; k < 2; ++k) if (p->scratch[k]) (void)hipFree(p->scratch[k]);
+    if (p->fin_prm) (void)hipFree(p->fin_prm);
+    if (p->fin_scratch) (void)hipFree(p->fin_scratch);
     free(p->bases);
     free(p);
     return PFB_OK;
