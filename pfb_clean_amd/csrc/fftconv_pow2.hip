@@ -1090,6 +1090,7 @@ int pow2_prepare(pfb_conv_plan* p) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         ft->num_cu = prop.multiProcessorCount;
     if (ft->num_cu <= 0) ft->num_cu = 256;
+    if (const char* e = getenv("PFB_CU_LIMIT")) { int v = atoi(e); if (v >= 16 && v < ft->num_cu) ft->num_cu = v; }   // experiments: leave CUs to a concurrent kernel
     return p->dtype == PFB_F32 ? prep_tables<float>(p, ft) : prep_tables<double>(p, ft);
 }
 
