@@ -56,6 +56,14 @@ struct pfb_psi_plan {
     void* fin_scratch;
     size_t fin_band, fin_basis;
     int fin_fmax;
+    // level kernels batched over the wavelet bases: parameter tables [level][wavelet basis] and a
+    // ping-pong scratch pair with one slice per wavelet basis
+    void* ana_prm;
+    void* syn_prm;
+    void* bscr[2];
+    size_t bscr_basis;
+    int nwb;
+    int gx_ana[pfb::MAXLEV], gy_ana[pfb::MAXLEV], gx_syn[pfb::MAXLEV], gy_syn[pfb::MAXLEV];
 };
 
 namespace pfb {
@@ -203,6 +211,152 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
     }
 }
 
+// ------------------------------------------------ level kernels batched over the bases
+// The coarse levels are tiny (level 3 of a 2048^2 image: 257^2 coefficients): launched basis by
+// basis they are launch/latency bound -- a third of psi.dot's time at config #4.  The batched
+// kernels take (band, wavelet basis) in blockIdx.z and a per-basis parameter table, so a level
+// costs ONE launch for all bases (different filter lengths are a workgroup-uniform switch).
+template <typename T> struct AnaPrm {           // analysis, one per (level, wavelet basis)
+    long long coeff_off, in_off, approx_off;    // offsets inside alpha's band / the scratch bases
+    int F, nxin, nyin, ldin, Cx, Cy, has_approx, pad_;
+    T lo[MAXF], hi[MAXF];                       // dec_lo, dec_hi
+};
+template <typename T> struct SynPrm {           // synthesis, one per (level >= 1, wavelet basis)
+    long long coeff_off, prev_off, out_off;
+    int F, nax, nay, has_prev, ldp, nxw, nyw, ldo;
+    T lo[MAXF], hi[MAXF];                       // rec_lo, rec_hi
+};
+
+// body of k_dwt_level for the tile (ox0, oy0); src / dst / approx already point at the band
+template <typename T, int F, int TA>
+__device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                         const T* __restrict__ src, int ldin, int nxin, int nyin,
+                                         T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
+                                         int ox0, int oy0) {
+
+    constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
+    constexpr int SA = NI + 1;                // LDS strides (odd -> conflict-free columns)
+    constexpr int SB = 2 * TA + 1;
+    T* A = smem;                              // [NI][SA]   input tile  A[lx][ly]
+    T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
+    T* LL = B + NI * SB;                      // [TA][TA+1] LL quadrant for the approx copy
+    const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
+    T lo[F], hi[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { lo[j] = flo[j]; hi[j] = fhi[j]; }
+    // 1. stage the input tile (zero extension outside the signal)
+    constexpr int VW = 16 / (int)sizeof(T);                      // elements per 16-byte access
+    if (ldin % VW == 0 && nyin % VW == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        // rows are 16-byte aligned (the finest level of an image whose width is a multiple of 4):
+        // aligned 16-byte loads of a slightly wider window -- 4x fewer load instructions, and every
+        // vector lies entirely inside or entirely outside [0, nyin)
+        struct alignas(16) Vec { T e[VW]; };
+        const int ga = gy0 - (((gy0 % VW) + VW) % VW);           // window start, rounded down
+        constexpr int NWV = (NI + 2 * (VW - 1) + VW - 1) / VW;   // vectors per tile row (upper bound)
+        constexpr int NLV = (NI * NWV + 255) / 256;
+        Vec stage[NLV];
+#pragma unroll
+        for (int k = 0; k < NLV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NWV, w = e - lx * NWV;
+            const int gx = gx0 + lx, gy = ga + VW * w;
+            Vec v;
+#pragma unroll
+            for (int c = 0; c < VW; ++c) v.e[c] = 0;
+            if (e < NI * NWV && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin)
+                v = *reinterpret_cast<const Vec*>(src + (size_t)gx * ldin + gy);
+            stage[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NLV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NWV, w = e - lx * NWV;
+            const int ly0 = ga - gy0 + VW * w;
+            if (e < NI * NWV) {
+#pragma unroll
+                for (int c = 0; c < VW; ++c)
+                    if (ly0 + c >= 0 && ly0 + c < NI) A[lx * SA + ly0 + c] = stage[k].e[c];
+            }
+        }
+    } else {
+        constexpr int NLD = (NI * NI + 255) / 256;
+        T stage[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NI, ly = e - lx * NI;
+            const int gx = gx0 + lx, gy = gy0 + ly;
+            T v = 0;
+            if (e < NI * NI && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
+            stage[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int lx = e / NI, ly = e - lx * NI;
+            if (e < NI * NI) A[lx * SA + ly] = stage[k];
+        }
+    }
+    __syncthreads();
+    // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
+    for (int e = threadIdx.x; e < NI * TA; e += 256) {
+        const int lx = e / TA, qq = e - lx * TA;
+        const T* a = A + lx * SA + 2 * qq + F - 1;
+        T sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) { const T v = a[-j]; sl += lo[j] * v; sh += hi[j] * v; }
+        B[lx * SB + qq] = sl;
+        B[lx * SB + TA + qq] = sh;
+    }
+    __syncthreads();
+    // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c (x coefficient) lo & hi
+    for (int e = threadIdx.x; e < 2 * TA * TA; e += 256) {
+        const int r = e / TA, cc = e - r * TA;
+        const T* b = B + (2 * cc + F - 1) * SB + r;
+        T sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) { const T v = b[-j * SB]; sl += lo[j] * v; sh += hi[j] * v; }
+        const bool hiy = r >= TA;
+        const int rr = hiy ? r - TA : r;
+        const int gy = oy0 + rr, gx = ox0 + cc;
+        if (gy < Cy && gx < Cx) {
+            T* row = dst + (size_t)((hiy ? Cy : 0) + gy) * ldc;
+            row[gx] = sl;
+            row[Cx + gx] = sh;
+        }
+        if (!hiy) LL[cc * (TA + 1) + rr] = sl;
+    }
+    if (approx) {
+        __syncthreads();
+        T* ap = approx;
+        for (int e = threadIdx.x; e < TA * TA; e += 256) {
+            const int cc = e / TA, rr = e - cc * TA;           // rr (y) fastest: coalesced
+            if (ox0 + cc < Cx && oy0 + rr < Cy) ap[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
+        }
+    }
+}
+
+template <typename T, int TA, int FMAX>
+__global__ void __launch_bounds__(256)
+k_dwt_batched(const T* __restrict__ in_base, size_t in_band, T* __restrict__ alpha, size_t aband, int ldc,
+              T* __restrict__ scr_out, size_t sband, const AnaPrm<T>* __restrict__ prm, int nwb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int j = blockIdx.z % nwb, band = blockIdx.z / nwb;
+    const AnaPrm<T>& P = prm[j];
+    const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
+    if (ox0 >= P.Cx || oy0 >= P.Cy) return;
+    const T* src = in_base + P.in_off + (size_t)band * in_band;
+    T* dst = alpha + (size_t)band * aband + P.coeff_off;
+    T* approx = P.has_approx ? scr_out + P.approx_off + (size_t)band * sband : nullptr;
+    switch (P.F) {
+#define X(FF) case FF: if constexpr (FF <= FMAX) dwt_tile<T, FF, TA>(reinterpret_cast<T*>(smem_raw), P.lo, P.hi, src, P.ldin, P.nxin, P.nyin, dst, ldc, P.Cx, P.Cy, approx, ox0, oy0); break;
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+        default: break;
+    }
+}
+
+
 // ----------------------------------------------------------------- synthesis level
 // coeffs : this level's (2 nay, 2 nax) block, ld = ldc (y-major)
 // prev   : if non-null, the approx quadrant is prev[c][r] (previous level's image,
@@ -307,6 +461,124 @@ k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int 
         }
     }
 }
+
+// body of k_idwt_level (store, no accumulate) for the output tile (ix0, iy0)
+template <typename T, int F, int TS>
+__device__ __forceinline__ void idwt_tile_store(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                                const T* __restrict__ src, int ldc, int nax, int nay,
+                                                const T* __restrict__ pv, int ldp, T* __restrict__ dst, int ldo,
+                                                int nxw, int nyw, int ix0, int iy0) {
+
+    constexpr int h = F / 2;
+    constexpr int NC = TS / 2 + h - 1;        // coefficients needed per half and tile edge
+    constexpr int SC = 2 * NC + 1;
+    constexpr int ST = TS + 1;
+    T* C = smem;                              // [2NC][SC]  C[ry][cx]  (lo|hi in both)
+    T* Tm = C + 2 * NC * SC;                  // [2NC][ST]  after the x pass  Tm[ry][ox]
+    const int mx0 = ix0 / 2, my0 = iy0 / 2;
+    T lo[F], hi[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { lo[j] = flo[j]; hi[j] = fhi[j]; }
+    // 1. stage coefficients (all loads first); rows/cols beyond (nay, nax) are only used by
+    //    cropped outputs.  coeffs are read row-wise (cx fastest), prev column-wise (ry fastest).
+    constexpr int NE = 4 * NC * NC;
+    constexpr int NLD = (NE + 255) / 256;
+    T stage[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+        const bool hy = ry >= NC, hx = cx >= NC;
+        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
+        T v = 0;
+        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
+            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+        stage[k] = v;
+    }
+    constexpr int NLP = (NC * NC + 255) / 256;
+    T stagep[NLP];
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;              // ry fastest: prev is read along y
+            const int gy = my0 + ry, gx = mx0 + cx;
+            T v = 0;
+            if (e < NC * NC && gy < nay && gx < nax) v = pv[(size_t)gx * ldp + gy];
+            stagep[k] = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
+    }
+    if (pv) {
+#pragma unroll
+        for (int k = 0; k < NLP; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            const int cx = e / NC, ry = e - cx * NC;
+            if (e < NC * NC) C[ry * SC + cx] = stagep[k];
+        }
+    }
+    __syncthreads();
+    // 2. x pass: Tm[ry][ox] = sum_j lo[2j+p] C[ry][m+h-1-j] + sum_j hi[2j+p] C[ry][NC+m+h-1-j]
+    //    (one thread makes the even/odd output pair from the same h taps)
+    for (int e = threadIdx.x; e < 2 * NC * (TS / 2); e += 256) {
+        const int ry = e / (TS / 2), m = e - ry * (TS / 2);
+        const T* c = C + ry * SC + m + h - 1;
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = c[-j], d = c[NC - j];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        Tm[ry * ST + 2 * m] = sl0 + sh0;
+        Tm[ry * ST + 2 * m + 1] = sl1 + sh1;
+    }
+    __syncthreads();
+    // 3. y pass + store (iy fastest); a thread makes the pair (2m, 2m+1) of one image row
+    for (int e = threadIdx.x; e < TS * (TS / 2); e += 256) {
+        const int ox = e / (TS / 2), m = e - ox * (TS / 2);
+        const T* t = Tm + (m + h - 1) * ST + ox;
+        T sl0 = 0, sh0 = 0, sl1 = 0, sh1 = 0;
+#pragma unroll
+        for (int j = 0; j < h; ++j) {
+            const T a = t[-j * ST], d = t[(NC - j) * ST];
+            sl0 += lo[2 * j] * a;     sh0 += hi[2 * j] * d;
+            sl1 += lo[2 * j + 1] * a; sh1 += hi[2 * j + 1] * d;
+        }
+        const int gx = ix0 + ox, gy = iy0 + 2 * m;
+        if (gx < nxw) {
+            T* q = dst + (size_t)gx * ldo + gy;
+            if (gy < nyw)     { q[0] = sl0 + sh0; }
+            if (gy + 1 < nyw) { q[1] = sl1 + sh1; }
+        }
+    }
+}
+
+template <typename T, int TS, int FMAX>
+__global__ void __launch_bounds__(256)
+k_idwt_batched(const T* __restrict__ alpha, size_t aband, int ldc, const T* __restrict__ scr_prev, size_t sband,
+               T* __restrict__ out_base, size_t oband, const SynPrm<T>* __restrict__ prm, int nwb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int j = blockIdx.z % nwb, band = blockIdx.z / nwb;
+    const SynPrm<T>& P = prm[j];
+    const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
+    if (ix0 >= P.nxw || iy0 >= P.nyw) return;
+    const T* src = alpha + (size_t)band * aband + P.coeff_off;
+    const T* pv = P.has_prev ? scr_prev + P.prev_off + (size_t)band * sband : nullptr;
+    T* dst = out_base + P.out_off + (size_t)band * oband;
+    switch (P.F) {
+#define X(FF) case FF: if constexpr (FF <= FMAX) idwt_tile_store<T, FF, TS>(reinterpret_cast<T*>(smem_raw), P.lo, P.hi, src, ldc, P.nax, P.nay, pv, P.ldp, dst, P.ldo, P.nxw, P.nyw, ix0, iy0); break;
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+        default: break;
+    }
+}
+
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_fill(T* p, size_t n, T v) {
@@ -671,8 +943,14 @@ static int set_wavelet_lds_limits() {
     return PFB_OK;
 }
 
+template <typename T> static int psi_dot_batched_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st);
+
 template <typename T>
 static int psi_dot_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st) {
+    {
+        const char* e = getenv("PFB_PSI_FUSED");
+        if (!(e && !atoi(e)) && p->nbasis > 0) return psi_dot_batched_t<T>(p, x, alpha, st);
+    }
     const size_t plane = (size_t)p->Nymax * p->Nxmax;
     const size_t aband = plane * p->nbasis;
     const size_t xband = (size_t)p->nx * p->ny;
@@ -745,10 +1023,103 @@ static int psi_fin_prepare(pfb_psi_plan* p) {
     PFB_HIP_CHECK(hipMemcpy(p->fin_prm, h.data(), sizeof(FinBasis<T>) * h.size(), hipMemcpyHostToDevice));
     PFB_HIP_CHECK(hipMalloc(&p->fin_scratch, sizeof(T) * p->fin_basis * p->nbasis));
     constexpr int TS = Tile<T>::TS;
+    constexpr int TA = Tile<T>::TA;
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 18>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_batched<T, TA, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_batched<T, TA, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_batched<T, TS, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_batched<T, TS, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // ---- batched level tables: [level][wavelet basis]
+    std::vector<int> wb;
+    for (int ib = 0; ib < p->nbasis; ++ib) if (p->bases[ib].K != 0) wb.push_back(ib);
+    p->nwb = (int)wb.size();
+    if (p->nwb == 0) return PFB_OK;
+    p->bscr_basis = p->scratch_band * p->nband;
+    for (int k = 0; k < 2; ++k)
+        PFB_HIP_CHECK(hipMalloc(&p->bscr[k], sizeof(T) * p->bscr_basis * p->nwb));
+    std::vector<AnaPrm<T>> ha((size_t)p->nlevel * p->nwb);
+    std::vector<SynPrm<T>> hs((size_t)p->nlevel * p->nwb);
+    for (int l = 0; l < p->nlevel; ++l) {
+        p->gx_ana[l] = p->gy_ana[l] = p->gx_syn[l] = p->gy_syn[l] = 1;
+        for (int j = 0; j < p->nwb; ++j) {
+            const int ib = wb[j];
+            const BasisInfo& b = p->bases[ib];
+            const LevelInfo& L = b.lev[l];
+            AnaPrm<T>& A = ha[(size_t)l * p->nwb + j];
+            memset(&A, 0, sizeof(A));
+            A.coeff_off = (long long)((size_t)ib * plane + (size_t)L.lowy * p->Nxmax + L.lowx);
+            A.in_off = l == 0 ? 0 : (long long)((size_t)j * p->bscr_basis);      // level 0 reads x
+            A.approx_off = (long long)((size_t)j * p->bscr_basis);
+            A.F = b.F; A.nxin = L.nxin; A.nyin = L.nyin;
+            A.ldin = l == 0 ? p->ny : b.lev[l - 1].Cy;
+            A.Cx = L.Cx; A.Cy = L.Cy;
+            A.has_approx = l < p->nlevel - 1;
+            SynPrm<T>& S = hs[(size_t)l * p->nwb + j];
+            memset(&S, 0, sizeof(S));
+            S.coeff_off = A.coeff_off;
+            S.F = b.F; S.nax = L.Cx; S.nay = L.Cy;
+            S.has_prev = l < p->nlevel - 1;
+            S.ldp = l < p->nlevel - 1 ? b.lev[l + 1].nyo : 0;
+            S.prev_off = (long long)((size_t)j * p->bscr_basis);
+            S.out_off = l == 1 ? (long long)((size_t)ib * p->fin_basis) : (long long)((size_t)j * p->bscr_basis);
+            S.nxw = L.nxo; S.nyw = L.nyo; S.ldo = L.nyo;
+            for (int k = 0; k < b.F; ++k) {
+                A.lo[k] = (T)b.filt[0][k]; A.hi[k] = (T)b.filt[1][k];
+                S.lo[k] = (T)b.filt[2][k]; S.hi[k] = (T)b.filt[3][k];
+            }
+            const int ga = (L.Cx + TA - 1) / TA, gb = (L.Cy + TA - 1) / TA;
+            if (ga > p->gx_ana[l]) p->gx_ana[l] = ga;
+            if (gb > p->gy_ana[l]) p->gy_ana[l] = gb;
+            const int gc = (L.nxo + TS - 1) / TS, gd = (L.nyo + TS - 1) / TS;
+            if (gc > p->gx_syn[l]) p->gx_syn[l] = gc;
+            if (gd > p->gy_syn[l]) p->gy_syn[l] = gd;
+        }
+    }
+    PFB_HIP_CHECK(hipMalloc(&p->ana_prm, sizeof(AnaPrm<T>) * ha.size()));
+    PFB_HIP_CHECK(hipMemcpy(p->ana_prm, ha.data(), sizeof(AnaPrm<T>) * ha.size(), hipMemcpyHostToDevice));
+    PFB_HIP_CHECK(hipMalloc(&p->syn_prm, sizeof(SynPrm<T>) * hs.size()));
+    PFB_HIP_CHECK(hipMemcpy(p->syn_prm, hs.data(), sizeof(SynPrm<T>) * hs.size(), hipMemcpyHostToDevice));
+    return PFB_OK;
+}
+
+// psi.dot with ONE launch per level for all wavelet bases (+ the 'self' transposes)
+template <typename T>
+static int psi_dot_batched_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t st) {
+    int rc = psi_fin_prepare<T>(p);
+    if (rc != PFB_OK) return rc;
+    const size_t plane = (size_t)p->Nymax * p->Nxmax;
+    const size_t aband = plane * p->nbasis;
+    const size_t xband = (size_t)p->nx * p->ny;
+    constexpr int TA = Tile<T>::TA;
+    for (int ib = 0; ib < p->nbasis; ++ib) {
+        if (p->bases[ib].K != 0) continue;
+        dim3 grid((p->ny + 31) / 32, (p->nx + 31) / 32, p->nband);
+        hipLaunchKernelGGL((k_transpose<T, false>), grid, dim3(256), 0, st, x, xband, p->ny,
+                           alpha + (size_t)ib * plane, aband, p->Nxmax, p->nx, p->ny);
+    }
+    if (p->nwb > 0) {
+        const size_t lds = dwt_lds<T>(p->fin_fmax);
+        for (int l = 0; l < p->nlevel; ++l) {
+            dim3 grid(p->gx_ana[l], p->gy_ana[l], p->nband * p->nwb);
+            const T* in = l == 0 ? x : (const T*)p->bscr[(l - 1) & 1];
+            const size_t in_band = l == 0 ? xband : p->scratch_band;
+            const AnaPrm<T>* prm = (const AnaPrm<T>*)p->ana_prm + (size_t)l * p->nwb;
+            if (p->fin_fmax <= 8)
+                hipLaunchKernelGGL((k_dwt_batched<T, TA, 8>), grid, dim3(256), lds, st, in, in_band, alpha, aband,
+                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, p->nwb);
+            else
+                hipLaunchKernelGGL((k_dwt_batched<T, TA, 18>), grid, dim3(256), lds, st, in, in_band, alpha, aband,
+                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, p->nwb);
+        }
+    }
+    PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
 
@@ -761,23 +1132,19 @@ static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t 
     const size_t aband = plane * p->nbasis;
     const size_t xband = (size_t)p->nx * p->ny;
     constexpr int TS = Tile<T>::TS;
-    for (int ib = 0; ib < p->nbasis; ++ib) {
-        const BasisInfo& b = p->bases[ib];
-        if (b.K == 0 || p->nlevel < 2) continue;
-        const Filt<T> f = make_filt<T>(b, 2, 3);
-        const T* ab = alpha + (size_t)ib * plane;
-        const T* prev = nullptr;
-        int ldp = 0;
-        for (int l = p->nlevel - 1; l >= 1; --l) {
-            const LevelInfo& L = b.lev[l];
-            const T* blk = ab + (size_t)L.lowy * p->Nxmax + L.lowx;
-            T* out = l == 1 ? (T*)p->fin_scratch + (size_t)ib * p->fin_basis : (T*)p->scratch[l & 1];
-            const size_t o_band = l == 1 ? p->fin_band : p->scratch_band;
-            dim3 grid((L.nxo + TS - 1) / TS, (L.nyo + TS - 1) / TS, p->nband);
-            launch_idwt<T, false>(b.F, grid, idwt_lds<T>(b.F), st, blk, aband, p->Nxmax, L.Cx, L.Cy, prev,
-                                  p->scratch_band, ldp, out, o_band, L.nyo, L.nxo, L.nyo, f);
-            prev = out;
-            ldp = L.nyo;
+    if (p->nwb > 0) {
+        const size_t ldsb = idwt_lds<T>(p->fin_fmax);
+        for (int l = p->nlevel - 1; l >= 1; --l) {       // coarse levels: one launch per level, all bases
+            dim3 g(p->gx_syn[l], p->gy_syn[l], p->nband * p->nwb);
+            const SynPrm<T>* prm = (const SynPrm<T>*)p->syn_prm + (size_t)l * p->nwb;
+            T* out = l == 1 ? (T*)p->fin_scratch : (T*)p->bscr[l & 1];
+            const size_t oband = l == 1 ? p->fin_band : p->scratch_band;
+            if (p->fin_fmax <= 8)
+                hipLaunchKernelGGL((k_idwt_batched<T, TS, 8>), g, dim3(256), ldsb, st, alpha, aband, p->Nxmax,
+                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb);
+            else
+                hipLaunchKernelGGL((k_idwt_batched<T, TS, 18>), g, dim3(256), ldsb, st, alpha, aband, p->Nxmax,
+                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb);
         }
     }
     dim3 grid((p->nx + TS - 1) / TS, (p->ny + TS - 1) / TS, p->nband);
@@ -799,9 +1166,8 @@ static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t 
 template <typename T>
 static int psi_hdot_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
     {
-        static int fused = -1;
-        if (fused < 0) { fused = 1; if (const char* e = getenv("PFB_PSI_FUSED")) fused = atoi(e) ? 1 : 0; }
-        if (fused && p->nbasis > 0) return psi_hdot_fused_t<T>(p, alpha, xo, st);
+        const char* e = getenv("PFB_PSI_FUSED");
+        if (!(e && !atoi(e)) && p->nbasis > 0) return psi_hdot_fused_t<T>(p, alpha, xo, st);
     }
     const size_t plane = (size_t)p->Nymax * p->Nxmax;
     const size_t aband = plane * p->nbasis;
@@ -954,6 +1320,9 @@ int pfb_psi_plan_destroy(pfb_psi_plan* p) {
     for (int k = 0; k < 2; ++k) if (p->scratch[k]) (void)hipFree(p->scratch[k]);
     if (p->fin_prm) (void)hipFree(p->fin_prm);
     if (p->fin_scratch) (void)hipFree(p->fin_scratch);
+    if (p->ana_prm) (void)hipFree(p->ana_prm);
+    if (p->syn_prm) (void)hipFree(p->syn_prm);
+    for (int k = 0; k < 2; ++k) if (p->bscr[k]) (void)hipFree(p->bscr[k]);
     free(p->bases);
     free(p);
     return PFB_OK;

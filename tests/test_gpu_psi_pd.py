@@ -275,3 +275,30 @@ def test_primal_dual_nonzero_margins_keep_reference_semantics(amd, golden):
                                         positivity=1, verbosity=0)
     assert maxerr(x, xo) < 1e-9 * np.abs(xo).max()
     assert maxerr(v, vo) < 1e-9 * np.abs(vo).max()
+
+
+@pytest.mark.parametrize('rdt', [np.float64, np.float32])
+def test_psi_batched_and_fused_kernels_match_per_basis_kernels(amd, rdt, monkeypatch):
+    """Default: one launch per level for all wavelet bases (k_dwt_batched / k_idwt_batched) and one
+    fused finest synthesis level (k_idwt_finest_fused).  PFB_PSI_FUSED=0 runs the per-basis kernels
+    instead; both must give the same coefficients / image (incl. db5+, the FMAX = 18 variants)."""
+    rng = np.random.default_rng(17)
+    nband, nx, ny = 3, 200, 168
+    for bases, nlevel in ((['self', 'db1', 'db2', 'db3', 'db4'], 3), (['db6', 'self', 'db2'], 2), (['db3'], 1)):
+        psi = amd.Psi(nband, nx, ny, bases, nlevel, 1, dtype=torch.float64 if rdt == np.float64 else torch.float32)
+        x = torch.from_numpy(rng.standard_normal((nband, nx, ny)).astype(rdt)).cuda()
+        shape = (nband, len(bases), psi.Nymax, psi.Nxmax)
+        a1 = torch.zeros(shape, dtype=x.dtype, device='cuda')
+        a0 = torch.zeros_like(a1)
+        psi.dot(x, a1)
+        c = torch.from_numpy(rng.standard_normal(shape).astype(rdt)).cuda()
+        y1 = torch.empty_like(x)
+        psi.hdot(c, y1)
+        monkeypatch.setenv('PFB_PSI_FUSED', '0')
+        psi.dot(x, a0)
+        y0 = torch.empty_like(x)
+        psi.hdot(c, y0)
+        monkeypatch.delenv('PFB_PSI_FUSED')
+        assert torch.equal(a0, a1)
+        tol = 1e-14 if rdt == np.float64 else 1e-6
+        assert (y0 - y1).abs().max().item() <= tol * y0.abs().max().item()
