@@ -243,6 +243,20 @@ int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void
                          double tau, int positivity, int nband, size_t npix,
                          void* x, double* sums, double* ws, void* stream);
 
+/* ------------------------------------------------------------ Clark CLEAN sub-minor loop
+ * pfb/deconv/clark.py:29-84 (subminor + subtract).  A: (nband, nact) active-set values, updated
+ * in place; Ip, Iq: (nact) int32 pixel indices of the active set; psf: (nband, nx_psf, ny_psf);
+ * model: (nband, nx, ny), receives gamma * component / wsums[band] at the chosen pixel for bands
+ * with wsums > 0; loop `while |sum_b A[b, pq]| > th and k < maxit` with pq the FIRST arg-max of
+ * (sum_b A)^2 like numpy.  The whole loop runs in one resident workgroup (no per-iteration
+ * launch); *iters_out (device int, may be NULL) receives the number of components taken.
+ * Needs nx_psf/2 >= nx - 1 and ny_psf/2 >= ny - 1 (the reference's overlap mask is then all
+ * true; for smaller PSFs the reference mis-indexes its shrunken active set), nband <= 64. */
+int pfb_clark_subminor(int dtype, void* A, size_t nact, int nband, const void* psf, int nx_psf,
+                       int ny_psf, const int* Ip, const int* Iq, void* model, int nx, int ny,
+                       const void* wsums, double gamma, double th, int maxit, int* iters_out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

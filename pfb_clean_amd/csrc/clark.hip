@@ -1,0 +1,117 @@
+// clark.hip -- the sub-minor loop of the Clark CLEAN (pfb/deconv/clark.py:29-84), the only part of
+// klean's minor cycle that is not an image-wide elementwise pass or the PSF convolution.
+//
+// The reference is a sequential greedy loop on the "active set" (pixels above the sub-minor
+// threshold): pick the pixel with the largest |sum over bands|, add gamma * component / wsum to
+// the model, subtract component * PSF(shift) from every active pixel, repeat (<= 1000 times).
+// Every iteration depends on the previous arg-max, so it is latency, not bandwidth: ONE resident
+// 1024-thread workgroup keeps the loop on the device -- one pass over the active set per
+// iteration (subtract and next search fused), two barriers, no launches.
+#include "common.hpp"
+
+namespace pfb {
+
+constexpr int CLK_T = 1024;
+constexpr int CLK_MAXBAND = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(CLK_T)
+k_clark_subminor(T* __restrict__ A, size_t nact, int nband, const T* __restrict__ psf, int P, int Q,
+                 const int* __restrict__ Ip, const int* __restrict__ Iq, T* __restrict__ model, int nx, int ny,
+                 const T* __restrict__ wsums, T gamma, T th, int maxit, int* __restrict__ iters_out) {
+    __shared__ T s_val[CLK_T / 64];
+    __shared__ long long s_idx[CLK_T / 64];
+    __shared__ T xh[CLK_MAXBAND];
+    __shared__ int s_p, s_q, s_go;
+    const int nxo2 = P / 2, nyo2 = Q / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int p = 0, q = 0, k = 0;
+    bool have_comp = false;             // iteration 0 only searches
+    for (;;) {
+        // ---- (subtract the component chosen last round and) search: max of (sum_b A[b,i])^2, first index wins
+        T best = T(-1);                  // NaN-safe: comparisons with NaN are false, index 0 stays valid
+        long long besti = 0;
+        for (size_t i = tid; i < nact; i += CLK_T) {
+            T s = 0;
+            if (have_comp) {
+                const int pp = nxo2 - (p - Ip[i]), qq = nyo2 - (q - Iq[i]);
+                const bool in = pp >= 0 && pp < P && qq >= 0 && qq < Q;      // always true for valid Ip, Iq
+                for (int b = 0; b < nband; ++b) {
+                    T a = A[(size_t)b * nact + i];
+                    if (in) a -= xh[b] * psf[((size_t)b * P + pp) * Q + qq];
+                    A[(size_t)b * nact + i] = a;
+                    s += a;
+                }
+            } else {
+                for (int b = 0; b < nband; ++b) s += A[(size_t)b * nact + i];
+            }
+            const T v = s * s;
+            if (v > best) { best = v; besti = (long long)i; }       // ascending i per thread: first max kept
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const T ov = __shfl_down(best, off, 64);
+            const long long oi = __shfl_down(besti, off, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            T bv = s_val[0];
+            long long bi = s_idx[0];
+            for (int w = 1; w < CLK_T / 64; ++w)
+                if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+            const T amax = sqrt(bv);         // NaN (all-NaN input or empty maxima) compares false: stop
+            int go = (amax > th && k < maxit && bi >= 0 && (size_t)bi < nact) ? 1 : 0;
+            int pn = 0, qn = 0;
+            if (go) {
+                pn = Ip[bi]; qn = Iq[bi];
+                if (pn < 0 || pn >= nx || qn < 0 || qn >= ny) go = 0;        // corrupt index arrays: stop, never write
+            }
+            s_go = go;
+            if (go) {
+                s_p = pn; s_q = qn;
+                for (int b = 0; b < nband; ++b) {
+                    const T c = A[(size_t)b * nact + (size_t)bi];
+                    xh[b] = c;
+                    if (wsums[b] > T(0)) model[((size_t)b * nx + pn) * ny + qn] += gamma * c / wsums[b];
+                }
+            }
+        }
+        __syncthreads();
+        if (!s_go) break;
+        p = s_p; q = s_q;
+        have_comp = true;
+        ++k;
+    }
+    if (tid == 0 && iters_out) *iters_out = k;
+}
+
+}  // namespace pfb
+
+using namespace pfb;
+
+extern "C" int pfb_clark_subminor(int dtype, void* A, size_t nact, int nband, const void* psf, int nx_psf, int ny_psf,
+                                  const int* Ip, const int* Iq, void* model, int nx, int ny, const void* wsums,
+                                  double gamma, double th, int maxit, int* iters_out, void* stream) {
+    PFB_REQUIRE(A && psf && Ip && Iq && model && wsums, PFB_ERR_INVALID, "clark_subminor: null argument");
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "clark_subminor: bad dtype");
+    PFB_REQUIRE(nband >= 1 && nband <= CLK_MAXBAND, PFB_ERR_UNSUPPORTED, "clark_subminor: nband %d > %d", nband, CLK_MAXBAND);
+    PFB_REQUIRE(nact >= 1, PFB_ERR_INVALID, "clark_subminor: empty active set");
+    // every offset p - Ip[i] must index the PSF: the reference masks |p - Ip| <= nx_psf/2 (and then
+    // mis-indexes its shrunken active set, clark.py:68-75); with nx_psf >= 2 nx - 1 the mask is all true
+    PFB_REQUIRE(nx_psf / 2 >= nx - 1 && ny_psf / 2 >= ny - 1 && nx_psf / 2 + nx - 1 < nx_psf && ny_psf / 2 + ny - 1 < ny_psf,
+                PFB_ERR_UNSUPPORTED, "clark_subminor: the PSF (%d,%d) must cover every offset of the (%d,%d) image", nx_psf,
+                ny_psf, nx, ny);
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_clark_subminor<float>), dim3(1), dim3(CLK_T), 0, st, (float*)A, nact, nband,
+                           (const float*)psf, nx_psf, ny_psf, Ip, Iq, (float*)model, nx, ny, (const float*)wsums,
+                           (float)gamma, (float)th, maxit, iters_out);
+    else
+        hipLaunchKernelGGL((k_clark_subminor<double>), dim3(1), dim3(CLK_T), 0, st, (double*)A, nact, nband,
+                           (const double*)psf, nx_psf, ny_psf, Ip, Iq, (double*)model, nx, ny, (const double*)wsums,
+                           gamma, th, maxit, iters_out);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}

@@ -33,6 +33,7 @@ from pfb.operators.psi import Psi  # noqa: E402
 from pfb.prox.prox_21m import (prox_21m, prox_21m_numba, dual_update,  # noqa: E402
                                dual_update_numba)
 from pfb.prox.prox_21 import prox_21  # noqa: E402
+from pfb.deconv.clark import clark, subminor  # noqa: E402
 import scipy.fft as sfft  # noqa: E402
 
 
@@ -385,7 +386,42 @@ def gen_dct():
     print('dct.npz', len(out))
 
 
+def gen_clark():
+    """Clark CLEAN minor cycle (deconv/clark.py): the sub-minor loop on its own and the full loop with
+    the PSF convolution, 2 bands, 32 x 32 image, 64 x 64 PSF (the reference's overlap mask is all true)."""
+    out = {}
+    rng = np.random.default_rng(490)
+    nb, nx, ny, P, Q = 2, 32, 32, 64, 64
+    u = (np.arange(P) - P // 2)[:, None]
+    v = (np.arange(Q) - Q // 2)[None, :]
+    wsums = np.array([0.6, 0.4])
+    psf = np.stack([np.exp(-(u ** 2 + v ** 2) / (2 * (1.5 + 0.3 * b) ** 2))
+                    * (1 + 0.15 * np.cos(0.7 * u) * np.cos(0.5 * v)) for b in range(nb)])
+    psf *= (wsums / psf[:, P // 2, Q // 2])[:, None, None]            # peak = wsum per band
+    psfhat = sfft.rfftn(sfft.ifftshift(psf, axes=(1, 2)), axes=(1, 2))
+    truth = np.zeros((nb, nx, ny))
+    truth[:, 8, 9] = [1.0, 0.9]
+    truth[:, 20, 22] = [0.6, 0.7]
+    truth[:, 21, 5] = [0.3, 0.25]
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    ID = psf_convolve_cube(xpad, xhat, xout, psfhat, Q, truth).copy() + 1e-3 * rng.standard_normal(truth.shape)
+    out.update(ID=ID, PSF=psf, PSFHAT=psfhat, wsums=wsums)
+    # sub-minor loop alone
+    IRsearch = np.sum(ID, axis=0) ** 2
+    subth = 0.3 * np.sqrt(IRsearch.max())
+    Ip, Iq = np.where(IRsearch > subth ** 2)
+    m = subminor(ID[:, Ip, Iq].copy(), psf, Ip, Iq, np.zeros_like(ID), wsums, gamma=0.1, th=subth, maxit=25)
+    out.update(sub_Ip=Ip, sub_Iq=Iq, sub_th=subth, sub_model=m.copy())
+    for tag, kw in (('a', dict(gamma=0.1, pf=0.05, maxit=6, subpf=0.5, submaxit=40)),
+                    ('b', dict(gamma=0.05, pf=0.3, maxit=50, subpf=0.7, submaxit=1000, threshold=0.0))):
+        model, status = clark(ID.copy(), psf, psfhat, wsums, verbosity=0, **kw)
+        out[f'clark_{tag}_model'] = model.copy()
+        out[f'clark_{tag}_status'] = status
+    np.savez_compressed(os.path.join(HERE, 'clark.npz'), **out)
+    print('clark.npz', len(out))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark']
     for w in which:
         globals()['gen_' + w]()

@@ -412,3 +412,43 @@ def test_band_sharded_cube_pcg_two_ranks_one_gpu():
             xr, kref = ref[tag]
             assert iters == kref, (tag, iters, kref)
             assert np.abs(x - xr[band0:band0 + nb]).max() < 1e-9 * np.abs(xr).max(), (rank, tag)
+
+
+@pytest.mark.parametrize('rdt', [np.float64, np.float32])
+def test_clark_minor_cycle(rdt):
+    """Clark CLEAN (deconv/clark.py) with the sub-minor loop in one resident workgroup and the
+    fused convolution, against the REFERENCE's outputs (tests/golden/clark.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.deconv.clark import clark
+    from pfb_clean_amd import _lib, _dev
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'clark.npz'))
+    cdt = np.complex128 if rdt == np.float64 else np.complex64
+    ID, PSF, PSFHAT, wsums = g['ID'].astype(rdt), g['PSF'].astype(rdt), g['PSFHAT'].astype(cdt), g['wsums'].astype(rdt)
+    dev = torch.device('cuda')
+    # the sub-minor loop alone through the C-ABI
+    lib = _lib.load()
+    Ip, Iq = g['sub_Ip'], g['sub_Iq']
+    A = torch.from_numpy(np.ascontiguousarray(ID[:, Ip, Iq])).to(dev)
+    model = torch.zeros(ID.shape, dtype=A.dtype, device=dev)
+    it = torch.zeros(1, dtype=torch.int32, device=dev)
+    psf_d, w_d = torch.from_numpy(PSF).to(dev), torch.from_numpy(wsums).to(dev)     # keep alive across the call
+    ip_d, iq_d = torch.from_numpy(Ip.astype(np.int32)).to(dev), torch.from_numpy(Iq.astype(np.int32)).to(dev)
+    _lib.check(lib.pfb_clark_subminor(_dev.code(A.dtype), _dev.ptr(A), A.shape[1], ID.shape[0],
+                                      _dev.ptr(psf_d), PSF.shape[1], PSF.shape[2], _dev.ptr(ip_d), _dev.ptr(iq_d),
+                                      _dev.ptr(model), ID.shape[1], ID.shape[2], _dev.ptr(w_d),
+                                      0.1, float(g['sub_th']), 25, _dev.ptr(it), _dev.stream()))
+    torch.cuda.synchronize()
+    tol = 1e-11 if rdt == np.float64 else 2e-4
+    assert it.item() > 3
+    assert np.abs(model.cpu().numpy() - g['sub_model']).max() < tol * np.abs(g['sub_model']).max()
+    # full minor cycle, numpy in -> numpy out and tensors in -> tensors out
+    for tag, kw in (('a', dict(gamma=0.1, pf=0.05, maxit=6, subpf=0.5, submaxit=40)),
+                    ('b', dict(gamma=0.05, pf=0.3, maxit=50, subpf=0.7, submaxit=1000, threshold=0.0))):
+        m, status = clark(ID.copy(), PSF, PSFHAT, wsums, verbosity=0, **kw)
+        ref = g[f'clark_{tag}_model']
+        assert status == int(g[f'clark_{tag}_status']) and isinstance(m, np.ndarray)
+        assert np.abs(m - ref).max() < tol * np.abs(ref).max(), tag
+    mt, _ = clark(torch.from_numpy(ID).to(dev), torch.from_numpy(PSF).to(dev), torch.from_numpy(PSFHAT).to(dev),
+                  torch.from_numpy(wsums).to(dev), verbosity=0, gamma=0.1, pf=0.05, maxit=6, subpf=0.5, submaxit=40)
+    assert mt.is_cuda and np.abs(mt.cpu().numpy() - g['clark_a_model']).max() < tol * np.abs(g['clark_a_model']).max()

@@ -416,3 +416,21 @@ def test_cg_dct_golden(golden):
             for i in keys:
                 assert_allclose(xs[f][i], g[f'{tag}_{f}_{i}_x'], rtol=1e-8, atol=1e-10)
                 assert_allclose(rs[f][i], g[f'{tag}_{f}_{i}_r'], rtol=1e-7, atol=1e-9)
+
+
+# ----------------------------------------------------------------- Clark CLEAN (8f3)
+def test_clark_golden(golden):
+    """deconv/clark.py:29-177 against the reference's own outputs (tests/golden/clark.npz)."""
+    from oracle import clark as ock
+    g = golden('clark')
+    ID, PSF, PSFHAT, wsums = g['ID'], g['PSF'], g['PSFHAT'], g['wsums']
+    Ip, Iq = g['sub_Ip'], g['sub_Iq']
+    m, k = ock.subminor(ID[:, Ip, Iq].copy(), PSF, Ip, Iq, np.zeros_like(ID), wsums, gamma=0.1,
+                        th=float(g['sub_th']), maxit=25)
+    assert k > 3
+    assert_allclose(m, g['sub_model'], rtol=1e-12, atol=1e-15)
+    for tag, kw in (('a', dict(gamma=0.1, pf=0.05, maxit=6, subpf=0.5, submaxit=40)),
+                    ('b', dict(gamma=0.05, pf=0.3, maxit=50, subpf=0.7, submaxit=1000, threshold=0.0))):
+        model, status = ock.clark(ID.copy(), PSF, PSFHAT, wsums, **kw)
+        assert status == int(g[f'clark_{tag}_status'])
+        assert_allclose(model, g[f'clark_{tag}_model'], rtol=1e-9, atol=1e-13)
