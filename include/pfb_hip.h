@@ -257,6 +257,13 @@ int pfb_clark_subminor(int dtype, void* A, size_t nact, int nband, const void* p
                        const void* wsums, double gamma, double th, int maxit, int* iters_out,
                        void* stream);
 
+/* Band coupling of the fwdbwd parametrisations, pfb/utils/misc.py:1366-1375 (freqmul):
+ * out[k, :] = [post[k, :] *] sum_l A[k, l] * ([pre[l, :] *] x[l, :]) over npix pixels; A: (nband, nband)
+ * row-major on the device; pre / post (nband, npix) or NULL fuse the elementwise factors of the 'exp'
+ * parametrisation (misc.py:1412-1416).  out must not alias x; nband <= 64. */
+int pfb_freqmul(int dtype, const void* A, const void* x, void* out, int nband, size_t npix,
+                const void* pre, const void* post, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,9 +87,55 @@ k_clark_subminor(T* __restrict__ A, size_t nact, int nband, const T* __restrict_
     if (tid == 0 && iters_out) *iters_out = k;
 }
 
+// ----------------------------------------------------------------- band coupling
+// freqmul (pfb/utils/misc.py:1366-1375): out[k, i, j] = sum_l A[k, l] x[l, i, j] -- the nband x nband
+// mixing of the fwdbwd parametrisations.  One thread per pixel: nband reads, nband writes, the
+// small matrix (<= 64 x 64) from LDS; HBM bound, no MFMA at these sizes.
+constexpr int FM_MAXBAND = 64;
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_freqmul(const T* __restrict__ A, const T* __restrict__ x, T* __restrict__ out, int nband, size_t npix,
+          const T* __restrict__ pre, const T* __restrict__ post) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);
+    for (int k = threadIdx.x; k < nband * nband; k += blockDim.x) As[k] = A[k];
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        T xv[FM_MAXBAND];
+#pragma unroll 1
+        for (int l = 0; l < nband; ++l) xv[l] = pre ? x[(size_t)l * npix + i] * pre[(size_t)l * npix + i] : x[(size_t)l * npix + i];
+#pragma unroll 1
+        for (int k = 0; k < nband; ++k) {
+            T s = 0;
+            for (int l = 0; l < nband; ++l) s += As[k * nband + l] * xv[l];       // same order as the reference loop
+            out[(size_t)k * npix + i] = post ? s * post[(size_t)k * npix + i] : s;
+        }
+    }
+}
+
 }  // namespace pfb
 
 using namespace pfb;
+
+extern "C" int pfb_freqmul(int dtype, const void* A, const void* x, void* out, int nband, size_t npix,
+                           const void* pre, const void* post, void* stream) {
+    PFB_REQUIRE(A && x && out && x != out, PFB_ERR_INVALID, "freqmul: bad argument (out must not alias x)");
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "freqmul: bad dtype");
+    PFB_REQUIRE(nband >= 1 && nband <= FM_MAXBAND, PFB_ERR_UNSUPPORTED, "freqmul: nband %d > %d", nband, FM_MAXBAND);
+    hipStream_t st = as_stream(stream);
+    size_t g = (npix + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    const size_t esz = dtype == PFB_F32 ? 4 : 8;
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_freqmul<float>), dim3((unsigned)g), dim3(256), esz * nband * nband, st, (const float*)A,
+                           (const float*)x, (float*)out, nband, npix, (const float*)pre, (const float*)post);
+    else
+        hipLaunchKernelGGL((k_freqmul<double>), dim3((unsigned)g), dim3(256), esz * nband * nband, st, (const double*)A,
+                           (const double*)x, (double*)out, nband, npix, (const double*)pre, (const double*)post);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
 
 extern "C" int pfb_clark_subminor(int dtype, void* A, size_t nact, int nband, const void* psf, int nx_psf, int ny_psf,
                                   const int* Ip, const int* Iq, void* model, int nx, int ny, const void* wsums,

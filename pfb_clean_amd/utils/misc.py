@@ -4,6 +4,7 @@ The three pfb/utils/misc.py helpers that sit on the hot path.
     norm_diff(x, xp)                      misc.py:1316-1351
     l1reweight_func(psiH, outvar, ...)    misc.py:1070-1080
     dds2cubes(dds, nband, ...)            misc.py:664-739   (cube assembly, device resident)
+    freqmul(A, x), setup_parametrisation  misc.py:1366-1423 (band coupling of the fwdbwd parametrisations)
 """
 import math
 
@@ -113,3 +114,70 @@ def dds2cubes(dds, nband, apparent=False, dual=True, modelname='MODEL'):
     nz = wsums != 0
     mean_beam[nz] /= wsums[nz][:, None, None]
     return dirty, model, residual, psf, psfhat, mean_beam, wsums, dualc
+
+
+def _freqmul(A, x, pre=None, post=None):
+    lib = _lib.load()
+    xd = _dev.to_dev(x).contiguous()
+    Ad = _dev.to_dev(A, xd.dtype).contiguous()
+    out = torch.empty_like(xd)
+    nband = xd.shape[0]
+    if tuple(Ad.shape) != (nband, nband):
+        raise ValueError(f"A must be ({nband},{nband})")
+    _lib.check(lib.pfb_freqmul(_dev.code(xd.dtype), _dev.ptr(Ad), _dev.ptr(xd), _dev.ptr(out), nband,
+                               xd[0].numel(), _dev.ptr(pre), _dev.ptr(post), _dev.stream()))
+    return out
+
+
+def freqmul(A, x):
+    """misc.py:1366-1375: out[k] = sum_l A[k, l] x[l] for an (nband, nx, ny) cube, on the GPU."""
+    out = _freqmul(A, x)
+    return out.cpu().numpy() if _dev.is_numpy(x) else out
+
+
+def setup_parametrisation(mode='id', minval=1e-5, sigma=1.0, freq=None, lscale=1.0):
+    """misc.py:1378-1423: x = f(s) with a squared-exponential band covariance K = L L^T.  Returns
+    (func, finv, dfunc, dhfunc) working on GPU tensors or numpy cubes; the nband x nband factor is
+    built on the host (numpy Cholesky), every cube-sized operation is one pfb_freqmul launch (the
+    exp / product factors of mode='exp' fused into it).  finv applies L^-1 through the same kernel
+    (the reference's scipy.solve_triangular on the cube)."""
+    nu = np.asarray(freq, dtype=np.float64) / np.mean(freq)
+    nband = nu.size
+    K = sigma ** 2 * np.exp(-(nu[:, None] - nu[None, :]) ** 2 / (2 * lscale ** 2))
+    L = np.linalg.cholesky(K + 1e-10 * np.eye(nband))
+    LH = np.ascontiguousarray(L.T)
+    Linv = np.linalg.solve(L, np.eye(nband))
+
+    def back(t, like):
+        return t.cpu().numpy() if _dev.is_numpy(like) else t
+
+    if mode == 'id':
+        def func(x):
+            return back(_freqmul(L, x), x)
+
+        def finv(x):
+            return back(_freqmul(Linv, x), x)
+
+        def dfunc(x0, v):
+            return back(_freqmul(L, v), v)
+
+        def dhfunc(x0, v):
+            return back(_freqmul(LH, v), v)
+    elif mode == 'exp':
+        def func(x):
+            return back(torch.exp(_freqmul(L, x)), x)
+
+        def finv(x):
+            t = _freqmul(Linv, x)
+            return back(torch.log(torch.clamp(torch.abs(t), min=minval)), x)
+
+        def dfunc(x0, v):
+            e = torch.exp(_freqmul(L, x0))
+            return back(_freqmul(L, v, post=e), v)                 # exp(L x0) * (L v)
+
+        def dhfunc(x0, v):
+            e = torch.exp(_freqmul(L, x0))
+            return back(_freqmul(LH, v, pre=e), v)                 # L^T (v * exp(L x0))
+    else:
+        raise ValueError(f"Unknown mode - {mode}")
+    return func, finv, dfunc, dhfunc

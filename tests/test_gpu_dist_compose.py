@@ -452,3 +452,48 @@ def test_clark_minor_cycle(rdt):
     mt, _ = clark(torch.from_numpy(ID).to(dev), torch.from_numpy(PSF).to(dev), torch.from_numpy(PSFHAT).to(dev),
                   torch.from_numpy(wsums).to(dev), verbosity=0, gamma=0.1, pf=0.05, maxit=6, subpf=0.5, submaxit=40)
     assert mt.is_cuda and np.abs(mt.cpu().numpy() - g['clark_a_model']).max() < tol * np.abs(g['clark_a_model']).max()
+
+
+@pytest.mark.parametrize('rdt', [np.float64, np.float32])
+def test_freqmul_and_parametrisations(rdt):
+    """misc.py:1366-1423 (freqmul, setup_parametrisation) against numpy; parity unpinned by a reference
+    fixture (the module cannot be imported here), the functions are 10 lines of arithmetic."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import freqmul, setup_parametrisation
+    rng = np.random.default_rng(8)
+    nband, nx, ny = 5, 37, 41
+    A = rng.standard_normal((nband, nband)).astype(rdt)
+    x = rng.standard_normal((nband, nx, ny)).astype(rdt)
+    tol = 1e-13 if rdt == np.float64 else 2e-6
+    ref = np.einsum('kl,lij->kij', A.astype(np.float64), x.astype(np.float64))
+    assert np.abs(freqmul(A, x) - ref).max() < tol * np.abs(ref).max()
+    xt = torch.from_numpy(x).cuda()
+    assert np.abs(freqmul(torch.from_numpy(A).cuda(), xt).cpu().numpy() - ref).max() < tol * np.abs(ref).max()
+    freq = np.linspace(1.0e9, 1.7e9, nband)
+    nu = freq / freq.mean()
+    K = 0.8 ** 2 * np.exp(-(nu[:, None] - nu[None, :]) ** 2 / (2 * 0.5 ** 2))
+    L = np.linalg.cholesky(K + 1e-10 * np.eye(nband))
+    mul = lambda M, v: np.einsum('kl,lij->kij', M, v.astype(np.float64))
+    for mode in ('id', 'exp'):
+        func, finv, dfunc, dhfunc = setup_parametrisation(mode=mode, sigma=0.8, freq=freq, lscale=0.5)
+        s0 = 0.3 * x
+        v = rng.standard_normal(x.shape).astype(rdt)
+        if mode == 'id':
+            want = (mul(L, s0), mul(L, v), mul(L.T, v))
+        else:
+            e = np.exp(mul(L, s0))
+            want = (e, e * mul(L, v), mul(L.T, v * e))
+        got = (func(s0), dfunc(s0, v), dhfunc(s0, v))
+        for g_, w_ in zip(got, want):
+            assert np.abs(g_ - w_).max() < 50 * tol * np.abs(w_).max()
+        y = want[0]                                 # finv as the reference writes it (for 'exp' it is NOT
+        Li = np.linalg.solve(L, np.eye(nband))      # the inverse of func: log(max(|L^-1 y|, minval)))
+        wf = mul(Li, y) if mode == 'id' else np.log(np.maximum(np.abs(mul(Li, y)), 1e-5))
+        gf = finv(y.astype(rdt))
+        assert np.abs(gf - wf).max() < (1e-7 if rdt == np.float64 else 5e-2) * max(1.0, np.abs(wf).max())
+        # adjointness <dfunc v, u> = <v, dhfunc u>
+        u = rng.standard_normal(x.shape).astype(rdt)
+        lhs = np.vdot(dfunc(s0, v).astype(np.float64), u.astype(np.float64))
+        rhs = np.vdot(v.astype(np.float64), dhfunc(s0, u).astype(np.float64))
+        assert abs(lhs - rhs) < 200 * tol * (np.linalg.norm(dfunc(s0, v)) * np.linalg.norm(u))
