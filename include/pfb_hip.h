@@ -257,6 +257,16 @@ int pfb_clark_subminor(int dtype, void* A, size_t nact, int nband, const void* p
                        const void* wsums, double gamma, double th, int maxit, int* iters_out,
                        void* stream);
 
+/* Hogbom CLEAN, pfb/deconv/hogbom.py:8-74.  IR (nband, nx, ny): on entry the dirty cube, on exit the
+ * residual; model (nband, nx, ny): zero on entry, receives the components; wsums (nband) = per-band PSF
+ * peak (hogbom.py:27), all > 0.  Loop `while IRmax > max(pf * IRmax0, threshold) and k < maxit`, peak =
+ * FIRST arg-max of (sum_b IR)^2.  work: device scratch of at least 17 KiB (loop state, arg-max partials).
+ * Synchronous (the host looks at the loop state every 64 iterations); *k_out / *irmax_out are HOST
+ * outputs.  The PSF must cover every shift: nx_psf/2 >= nx - 1, ny_psf/2 >= ny - 1. */
+int pfb_hogbom(int dtype, void* IR, const void* psf, void* model, const void* wsums, int nband, int nx,
+               int ny, int nx_psf, int ny_psf, double gamma, double pf, double threshold, int maxit,
+               void* work, size_t work_bytes, int* k_out, double* irmax_out, void* stream);
+
 /* Band coupling of the fwdbwd parametrisations, pfb/utils/misc.py:1366-1375 (freqmul):
  * out[k, :] = [post[k, :] *] sum_l A[k, l] * ([pre[l, :] *] x[l, :]) over npix pixels; A: (nband, nband)
  * row-major on the device; pre / post (nband, npix) or NULL fuse the elementwise factors of the 'exp'

@@ -66,3 +66,31 @@ def clark(ID, PSF, PSFHAT, wsums, threshold=0, gamma=0.05, pf=0.05, maxit=50, su
         if np.abs(IRmaxp - IRmax) / np.abs(IRmaxp) < 1e-3:
             stall_count += stall_count
     return model, (1 if (k >= maxit or stall_count >= 5) else 0)
+
+
+def hogbom(ID, PSF, threshold=0, gamma=0.1, pf=0.1, maxit=10000):
+    """pfb/deconv/hogbom.py:8-74.  Returns (model, status, residual)."""
+    nband, nx, ny = ID.shape
+    _, nx_psf, ny_psf = PSF.shape
+    nx0, ny0 = nx_psf // 2, ny_psf // 2
+    x = np.zeros((nband, nx, ny), dtype=ID.dtype)
+    IR = ID.copy()
+    IRsearch = np.sum(IR, axis=0) ** 2
+    pq = IRsearch.argmax()
+    p = pq // ny
+    q = pq - p * ny
+    IRmax = np.sqrt(IRsearch[p, q])
+    wsums = np.amax(PSF, axis=(1, 2))
+    tol = np.maximum(pf * IRmax, threshold)
+    k = 0
+    while IRmax > tol and k < maxit:
+        xhat = IR[:, p, q] / wsums
+        x[:, p, q] += gamma * xhat
+        IR = IR - gamma * xhat[:, None, None] * PSF[:, nx0 - p:nx0 + nx - p, ny0 - q:ny0 + ny - q]
+        IRsearch = np.sum(IR, axis=0) ** 2
+        pq = IRsearch.argmax()
+        p = pq // ny
+        q = pq - p * ny
+        IRmax = np.sqrt(IRsearch[p, q])
+        k += 1
+    return x, (1 if k >= maxit else 0), IR

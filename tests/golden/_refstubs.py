@@ -157,4 +157,5 @@ def install(repo_root):
     sys.path.insert(0, '/root/reference')
     import pfb  # noqa: F401  (no import-time side effects, pfb/__init__.py:33-137)
     pu = _mod('pfb.utils')
-    pu.misc = _mod('pfb.utils.misc', norm_diff=_norm_diff)
+    # give_edges: imported by deconv/hogbom.py:3 but never called there
+    pu.misc = _mod('pfb.utils.misc', norm_diff=_norm_diff, give_edges=None)

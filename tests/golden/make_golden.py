@@ -34,6 +34,7 @@ from pfb.prox.prox_21m import (prox_21m, prox_21m_numba, dual_update,  # noqa: E
                                dual_update_numba)
 from pfb.prox.prox_21 import prox_21  # noqa: E402
 from pfb.deconv.clark import clark, subminor  # noqa: E402
+from pfb.deconv.hogbom import hogbom  # noqa: E402
 import scipy.fft as sfft  # noqa: E402
 
 
@@ -417,6 +418,10 @@ def gen_clark():
         model, status = clark(ID.copy(), psf, psfhat, wsums, verbosity=0, **kw)
         out[f'clark_{tag}_model'] = model.copy()
         out[f'clark_{tag}_status'] = status
+    for tag, kw in (('a', dict(gamma=0.1, pf=0.1, maxit=10000)), ('b', dict(gamma=0.2, pf=0.01, maxit=37))):
+        model, status = hogbom(ID.copy(), psf, verbosity=0, **kw)
+        out[f'hogbom_{tag}_model'] = model.copy()
+        out[f'hogbom_{tag}_status'] = status
     np.savez_compressed(os.path.join(HERE, 'clark.npz'), **out)
     print('clark.npz', len(out))
 

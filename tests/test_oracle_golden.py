@@ -434,3 +434,13 @@ def test_clark_golden(golden):
         model, status = ock.clark(ID.copy(), PSF, PSFHAT, wsums, **kw)
         assert status == int(g[f'clark_{tag}_status'])
         assert_allclose(model, g[f'clark_{tag}_model'], rtol=1e-9, atol=1e-13)
+
+
+def test_hogbom_golden(golden):
+    """deconv/hogbom.py:8-74 against the reference's own outputs (tests/golden/clark.npz)."""
+    from oracle import clark as ock
+    g = golden('clark')
+    for tag, kw in (('a', dict(gamma=0.1, pf=0.1, maxit=10000)), ('b', dict(gamma=0.2, pf=0.01, maxit=37))):
+        model, status, _ = ock.hogbom(g['ID'].copy(), g['PSF'], **kw)
+        assert status == int(g[f'hogbom_{tag}_status'])
+        assert_allclose(model, g[f'hogbom_{tag}_model'], rtol=1e-11, atol=1e-14)
