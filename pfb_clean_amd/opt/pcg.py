@@ -26,7 +26,6 @@ import os
 import sys
 import threading
 
-import numpy as np
 import torch
 
 from .. import _lib, _dev

@@ -26,7 +26,6 @@ non-positive in ANY band) all-reduces its mask.  Every rank takes the same decis
 import math
 import sys
 
-import numpy as np
 import torch
 
 from .. import _lib, _dev
@@ -43,8 +42,6 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     as_numpy = _dev.is_numpy(x)
     xd = _dev.to_dev(x).contiguous()
     vd = _dev.to_dev(v, xd.dtype).contiguous()
-    if as_numpy or xd is not x:
-        pass                                     # device copies; written back at the end
     dt = xd.dtype
     code = _dev.code(dt)
     nband = xd.shape[0]
