@@ -306,7 +306,7 @@ __global__ void k_set_beta(double* S) { S[S_BETA] = S[S_RHON] / S[S_RHO]; }
 __global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
 
 // ---- device-side loop bookkeeping of the sync-free driver
-__global__ void k_iter_begin(double* S, double mdiv, int predict) {
+__device__ __forceinline__ void iter_begin_dev(double* S, double mdiv, int predict) {
     if (S[S_DEAD] != 0.0) return;
     if (S[S_ANY] == 0.0) {                 // the direction built last iteration is all zero:
         S[S_DEAD] = 1.0;                   // the reference broke BEFORE k += 1 (pcg.py:106-108)
@@ -329,7 +329,7 @@ __global__ void k_iter_begin(double* S, double mdiv, int predict) {
         S[S_BETA] = (rho + (2.0 * alpha * S[S_RAP] + alpha * alpha * S[S_APAP]) / d) / rho;
     }
 }
-__global__ void k_iter_end(double* S, int fused) {
+__device__ __forceinline__ void iter_end_dev(double* S, int fused) {
     if (S[S_DEAD] != 0.0) return;
     if (!fused) S[S_BETA] = S[S_RHON] / S[S_RHO];
     S[S_RHO] = S[S_RHON];
@@ -337,6 +337,25 @@ __global__ void k_iter_end(double* S, int fused) {
     S[S_EPSP] = S[S_EPS];
     S[S_EPS] = sqrt(S[S_NUM] / (1e-12 + S[S_DEN]));
     S[S_NBTSUM] += S[S_NBT];
+}
+// the fused update's four sums AND the end-of-iteration bookkeeping in one launch (no all-reduce between)
+__global__ void __launch_bounds__(256)
+k_final_sum_waves_end(const double* __restrict__ ws, int G, double* __restrict__ S) {
+    const int q = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int dst[4] = {S_RHON, S_NUM, S_DEN, S_ANY};
+    double acc = 0.0;
+    for (int g = lane; g < G; g += 64) acc += ws[(size_t)q * G + g];
+    acc = wave_sum(acc);
+    if (lane == 0) S[dst[q]] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) iter_end_dev(S, 1);
+}
+__global__ void k_iter_begin(double* S, double mdiv, int predict) { iter_begin_dev(S, mdiv, predict); }
+__global__ void k_iter_end(double* S, int fused) { iter_end_dev(S, fused); }
+// end of iteration k and begin of iteration k+1 in one launch (the merged all-reduce path)
+__global__ void k_iter_end_begin(double* S, double mdiv, int predict) {
+    iter_end_dev(S, 1);
+    iter_begin_dev(S, mdiv, predict);
 }
 __global__ void k_final_check(double* S) {
     if (S[S_DEAD] == 0.0 && S[S_ANY] == 0.0) { S[S_DEAD] = 1.0; S[S_K] -= 1.0; S[S_EPS] = S[S_EPSP]; }
@@ -508,29 +527,36 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
             else
                 err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
             if (err != PFB_OK) return err;
+            bool begun = false;
             if (pending_end) {
                 // the previous iteration left [r'.y', |x'-x|^2, |x'|^2] un-reduced: they sit right
                 // behind [p.Ap, r.Ap, Ap.Ap, any(p)] in S, so ONE all-reduce of 7 scalars serves
                 // both reduction points (sharded bands: one RCCL call per iteration instead of two)
                 if ((err = reduce_hook(S_PAP, 7)) != PFB_OK) return err;
-                hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                hipLaunchKernelGGL(k_iter_end_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
                 pending_end = false;
+                begun = true;
             } else if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
             if (fuse_dir) {
                 // needs <r,Ap>, <Ap,Ap> even without backtracking (beta comes from rho(alpha))
-                hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
+                if (!begun)
+                    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
                 PFB_LAUNCH_VEC(T, k_pcg_update_dir, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
                                (const T*)rcur, p, (const T*)Ap, xnew, rnew,
                                (const double*)(S + S_ALPHA), mdiv);
+                if (!allreduce) {
+                    hipLaunchKernelGGL(k_final_sum_waves_end, dim3(1), dim3(256), 0, st, ws, G_used, S);
+                } else {
                 hipLaunchKernelGGL(k_final_sum_waves, dim3(1), dim3(256), 0, st, ws, G_used, 4, S,
                                    (Dst4{{S_RHON, S_NUM, S_DEN, S_ANY}}));
                 // nobody looks at k / eps before the next iteration while k < minit: fold this
                 // reduction point into the next iteration's (only worth it with a real all-reduce)
-                if (allreduce && khost + 1 < minit && khost + 1 < maxit) {
+                if (khost + 1 < minit && khost + 1 < maxit) {
                     pending_end = true;
                 } else {
                     if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
                     hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
+                }
                 }
                 { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
             } else {
