@@ -142,6 +142,13 @@ class PsfConvPlan:
         if p.ndim != 3 or p.dtype not in (torch.float32, torch.float64):
             raise ValueError("psf must be a real (nband, nx_psf, ny_psf) or (nx_psf, ny_psf) array")
         p = p.contiguous()
+        if _embed_grid(int(nx), int(ny), int(p.shape[1]), int(p.shape[2]), p.dtype) is not None:
+            # not a fast-path size: transform on the PSF's own grid first, then let the constructor
+            # re-grid it onto the power-of-two plan (operators/fft.py picks the native producer)
+            from .fft import psfhat_from_psf
+            ph = psfhat_from_psf(p)
+            plan = cls(ph, nx, ny, int(p.shape[2]))
+            return (plan, ph) if want_psfhat else plan
         self = cls.__new__(cls)
         self.embed = None
         self.nband, self.nx_psf, self.lastsize = (int(v) for v in p.shape)

@@ -515,3 +515,23 @@ def test_hogbom(rdt):
         assert np.abs(m - ref).max() < tol * np.abs(ref).max(), tag
     mt, _ = hogbom(torch.from_numpy(ID).cuda(), torch.from_numpy(PSF).cuda(), verbosity=0, gamma=0.2, pf=0.01, maxit=37)
     assert mt.is_cuda and np.abs(mt.cpu().numpy() - g['hogbom_b_model']).max() < tol * np.abs(g['hogbom_b_model']).max()
+
+
+def test_plan_from_psf_for_embedded_sizes():
+    """PsfConvPlan.from_psf on a size that is not a fast-path size: native PSFHAT, then the re-gridded plan."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    rng = np.random.default_rng(4)
+    nb, nx, ny = 2, 100, 120
+    P, Q = 2 * nx, 2 * ny
+    psf = rng.standard_normal((nb, P, Q))
+    ref_hat = ofc.psfhat_from_psf(psf)
+    plan, ph = PsfConvPlan.from_psf(torch.from_numpy(psf).cuda(), nx, ny, want_psfhat=True)
+    assert plan.embed == (128, 128) and plan.fast_path
+    assert np.abs(ph.cpu().numpy() - ref_hat).max() < 1e-12 * np.abs(ref_hat).max()
+    x = rng.standard_normal((nb, nx, ny))
+    xpad, xhat, xout = ofc.make_scratch(ref_hat, Q, x.shape, np.float64)
+    want = ofc.psf_convolve_cube(xpad, xhat, xout, ref_hat, Q, x)
+    got = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
