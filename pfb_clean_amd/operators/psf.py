@@ -201,9 +201,17 @@ class PsfConvPlan:
         if dot_with is not None:
             dot_with = dot_with.contiguous()
         if self.embed is not None:
-            xs, bs = self._pad(x3, nb), (None if beam is None else self._pad(beam, nb))
+            # padded input / output buffers are kept per band count: the margins of the input buffer are
+            # written once (zeros) and never touched again, so a call costs one copy in and one copy out
+            cache = self.__dict__.setdefault('_pad_cache', {})
+            key = (nb, x3.device)
+            if key not in cache:
+                cache[key] = (torch.zeros((nb,) + self.embed, dtype=self.rdtype, device=x3.device),
+                              torch.empty((nb,) + self.embed, dtype=self.rdtype, device=x3.device))
+            xs, os_ = cache[key]
+            xs[:, :self.nx, :self.ny] = x3
+            bs = None if beam is None else self._pad(beam, nb)
             ds = None if dot_with is None else self._pad(dot_with if dot_with.ndim == 3 else dot_with[None], nb)
-            os_ = torch.empty_like(xs)
         else:
             xs, bs, ds, os_ = x3, beam, dot_with, out3
         _lib.check(self._lib.pfb_psfconv_apply(
