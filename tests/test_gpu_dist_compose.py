@@ -535,3 +535,41 @@ def test_plan_from_psf_for_embedded_sizes():
     want = ofc.psf_convolve_cube(xpad, xhat, xout, ref_hat, Q, x)
     got = plan.apply(torch.from_numpy(x).cuda()).cpu().numpy()
     assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Error behaviour of the round's later C-ABI entry points: status codes + message, nothing launched."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd import _lib, _dev
+    from pfb_clean_amd._lib import PfbHipError
+    from pfb_clean_amd.deconv.hogbom import hogbom
+    from pfb_clean_amd.deconv.clark import clark
+    lib = _lib.load()
+    dev = torch.device('cuda')
+    a = torch.zeros((2, 16), dtype=torch.float64, device=dev)
+    psf_small = torch.ones((2, 8, 8), dtype=torch.float64, device=dev)       # cannot cover a 16 x 16 image
+    idx = torch.zeros(16, dtype=torch.int32, device=dev)
+    model = torch.zeros((2, 16, 16), dtype=torch.float64, device=dev)
+    w = torch.full((2,), 0.5, dtype=torch.float64, device=dev)
+    rc = lib.pfb_clark_subminor(1, _dev.ptr(a), 16, 2, _dev.ptr(psf_small), 8, 8, _dev.ptr(idx), _dev.ptr(idx),
+                                _dev.ptr(model), 16, 16, _dev.ptr(w), 0.1, 0.0, 10, None, _dev.stream())
+    assert rc == _lib.PFB_ERR_UNSUPPORTED and b'must cover' in lib.pfb_last_error()
+    rc = lib.pfb_clark_subminor(1, None, 16, 2, _dev.ptr(psf_small), 8, 8, _dev.ptr(idx), _dev.ptr(idx),
+                                _dev.ptr(model), 16, 16, _dev.ptr(w), 0.1, 0.0, 10, None, _dev.stream())
+    assert rc == -1
+    with pytest.raises(PfbHipError):
+        hogbom(np.ones((2, 16, 16)), np.ones((2, 8, 8)), verbosity=0)
+    with pytest.raises(ValueError):
+        hogbom(np.ones((2, 16, 16)), np.zeros((2, 32, 32)), verbosity=0)     # PSF peaks must be positive
+    with pytest.raises(AssertionError):
+        clark(np.ones((2, 16, 16)), np.ones((2, 32, 32)), np.ones((2, 32, 17), complex), np.array([0.7, 0.7]), verbosity=0)
+    # regrid: target grid too small for the image, and a line that does not fit the LDS
+    ph = torch.zeros((1, 32, 17), dtype=torch.complex128, device=dev)
+    out = torch.zeros((1, 32, 17), dtype=torch.complex128, device=dev)
+    assert lib.pfb_psfhat_regrid(1, _dev.ptr(ph), 1, 20, 20, 32, 32, 32, 32, _dev.ptr(out), _dev.stream()) == -1
+    assert lib.pfb_psfhat_regrid(1, _dev.ptr(ph), 1, 8, 8, 32, 32, 16384, 32, _dev.ptr(out), _dev.stream()) \
+        == _lib.PFB_ERR_UNSUPPORTED
+    x = torch.zeros((2, 4, 4), dtype=torch.float64, device=dev)
+    A = torch.eye(2, dtype=torch.float64, device=dev)
+    assert lib.pfb_freqmul(1, _dev.ptr(A), _dev.ptr(x), _dev.ptr(x), 2, 16, None, None, _dev.stream()) == -1   # aliasing
