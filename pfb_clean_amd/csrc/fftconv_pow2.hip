@@ -502,9 +502,9 @@ __device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm,
     }
 }
 
-template <typename T, int L>
+template <typename T, int L, bool BEAM>
 __global__ void __launch_bounds__(1024)
-k_row_fwd_pow2p(const T* __restrict__ x, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
+k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
                 cplx<T> wq1) {
     using P = FwdP<T, L>;
@@ -519,13 +519,19 @@ k_row_fwd_pow2p(const T* __restrict__ x, cplx<T>* __restrict__ Tw, const cplx<T>
     if (vb >= ntiles) return;
     for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptwc[k];
     for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
-    V2 xa[E];
+    V2 xa[E], ba[BEAM ? E : 1];
     {
         const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
         const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
-        const V2* xr = reinterpret_cast<const V2*>(x + ((size_t)bl * d.nx + (i0 + g)) * d.ny) + t;
+        const size_t off = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+        const V2* xr = reinterpret_cast<const V2*>(x + off) + t;
 #pragma unroll
         for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+        if constexpr (BEAM) {
+            const V2* br = reinterpret_cast<const V2*>(beam + off) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) ba[j] = br[TPB * j];
+        }
     }
     __syncthreads();                                    // tables visible
     for (;;) {
@@ -539,7 +545,9 @@ k_row_fwd_pow2p(const T* __restrict__ x, cplx<T>* __restrict__ Tw, const cplx<T>
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                vv[0][j] = cplx<T>(xa[j].x, xa[j].y);            // z[n] = x[2n] + i x[2n+1]
+                V2 a = xa[j];
+                if constexpr (BEAM) { a.x *= ba[j].x; a.y *= ba[j].y; }
+                vv[0][j] = cplx<T>(a.x, a.y);                    // z[n] = x[2n] + i x[2n+1]
                 vv[1][j] = vv[0][j] * ltm[t + TPB * j];          // z .* w_M^n  (odd bins)
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -562,6 +570,14 @@ k_row_fwd_pow2p(const T* __restrict__ x, cplx<T>* __restrict__ Tw, const cplx<T>
         {
             const int tid = launder((int)threadIdx.x);
             fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+        }
+        if constexpr (BEAM) {           // the next tile's beam rows: requested once the even-bin registers are free
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+            const V2* br = reinterpret_cast<const V2*>(beam + ((size_t)bln * d.nx + (i0n + g)) * d.ny) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) ba[j] = br[TPB * j];
         }
         {
             const int tid = launder((int)threadIdx.x);
@@ -819,10 +835,10 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
 }
 
 // MODE 0: no inner products; 1: <x, out>, <out, out>; 2: also <dot_with2, out> (the PCG call)
-template <typename T, int L, int E, int MODE>
+template <typename T, int L, int E, int MODE, bool BEAM>
 __global__ void __launch_bounds__((InvP<T, L, E>::NT))
 k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
-                const cplx<T>* __restrict__ ptw, const T* __restrict__ x,
+                const cplx<T>* __restrict__ ptw, const T* __restrict__ x, const T* __restrict__ beam,
                 const T* __restrict__ dot_with2, T* __restrict__ out,
                 double* __restrict__ partials, FastDims d, int band0, int tiles_per_band, int ntiles,
                 T scale, T sigmainv, cplx<T> wq1) {
@@ -876,7 +892,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             for (int j = 0; j < E; ++j) park[j * NT + tid] = vv[j];
         }
         // ---- odd bins
-        V2 xq[E], rq[E];
+        V2 xq[E], rq[E], bq[BEAM ? E : 1];
         {
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
@@ -890,6 +906,11 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             for (int j = 0; j < E; ++j) {
                 xq[j] = xr[TPB * j];
                 if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
+            }
+            if constexpr (BEAM) {
+                const V2* br = reinterpret_cast<const V2*>(beam + rowoff) + t;
+#pragma unroll
+                for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
             }
             inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, rr, bi, y);
             __syncthreads();
@@ -907,8 +928,13 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T> zz = park[j * NT + tid] + mulc(vv[j], ltm[t + TPB * j]);
                 V2 val;
                 const V2 xx = xq[j];
-                val.x = zz.x * scale + sigmainv * xx.x;
-                val.y = zz.y * scale + sigmainv * xx.y;
+                if constexpr (BEAM) {
+                    val.x = zz.x * scale * bq[j].x + sigmainv * xx.x;
+                    val.y = zz.y * scale * bq[j].y + sigmainv * xx.y;
+                } else {
+                    val.x = zz.x * scale + sigmainv * xx.x;
+                    val.y = zz.y * scale + sigmainv * xx.y;
+                }
                 orow[TPB * j] = val;
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
@@ -976,12 +1002,12 @@ template <typename T, int L>
 static int set_invp_attr() {
     constexpr int E = RowCfg<T, L, true>::E;
     if constexpr (InvP<T, L, E>::OK) {
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 0>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 1>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2p<T, L, E, 2>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define PFB_INVATTR(MODE, BM)                                                                           \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_inv_pow2p<T, L, E, MODE, BM>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        PFB_INVATTR(0, false); PFB_INVATTR(1, false); PFB_INVATTR(2, false);
+        PFB_INVATTR(0, true);  PFB_INVATTR(1, true);  PFB_INVATTR(2, true);
+#undef PFB_INVATTR
     }
     return PFB_OK;
 }
@@ -991,7 +1017,9 @@ static int prep_fwdp(void** table) {
     if constexpr (FwdP<T, L>::OK) {
         int rc = prep_ptw_compact<T, L, FwdP<T, L>::EOK>(table);
         if (rc != PFB_OK) return rc;
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2p<T, L>,
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return PFB_OK;
@@ -1162,15 +1190,20 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, in
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
     if constexpr (FwdP<T, L>::OK) {
-        if (ft->fwd_persistent && !beam) {
+        if (ft->fwd_persistent) {
             using FP = FwdP<T, L>;
             const int tiles_per_band = p->nx / FP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
-            hipLaunchKernelGGL((k_row_fwd_pow2p<T, L>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
-                               (cplx<T>*)p->T, (const cplx<T>*)ft->twM, (const cplx<T>*)ft->ptwc_row_fwd, d,
-                               band0, tiles_per_band, ntiles, wq1);
+            if (beam)
+                hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, true>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
+                                   (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)ft->twM,
+                                   (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
+            else
+                hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, false>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
+                                   (const T*)nullptr, (cplx<T>*)p->T, (const cplx<T>*)ft->twM,
+                                   (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
             return;
         }
     }
@@ -1191,23 +1224,25 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     if constexpr (InvP<T, L, E>::OK) {
         // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
         const bool plain_dots = !dot_with || (dot_with == x);
-        if (ft->inv_persistent && !beam && plain_dots && !(dot_with2 && !dot_with)) {
+        if (ft->inv_persistent && plain_dots && !(dot_with2 && !dot_with)) {
             using IP = InvP<T, L, E>;
             const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
-#define PFB_INVP(MODE)                                                                                  \
-            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
+#define PFB_INVP2(MODE, BM)                                                                             \
+            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE, BM>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
                                (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
-                               (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)dot_with2,       \
-                               (T*)out, p->partials, d, band0, tiles_per_band, ntiles, (T)scale,        \
-                               (T)sigmainv, wq1)
+                               (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam,            \
+                               (const T*)dot_with2, (T*)out, p->partials, d, band0, tiles_per_band,     \
+                               ntiles, (T)scale, (T)sigmainv, wq1)
+#define PFB_INVP(MODE) do { if (beam) PFB_INVP2(MODE, true); else PFB_INVP2(MODE, false); } while (0)
             p->last_npartials = grid;
             if (!dot_with) PFB_INVP(0);
             else if (!dot_with2) PFB_INVP(1);
             else PFB_INVP(2);
 #undef PFB_INVP
+#undef PFB_INVP2
             return;
         }
     }

@@ -140,13 +140,14 @@ def test_conv_tensor_path_and_fused_dot(amd, shape):
     assert relerr(out1[0].cpu().numpy(), ref1) < 1e-12
 
 
+@pmp('with_beam', [False, True])
 @pmp('ny', [4096, 2048])
 @pmp('mode', [0, 1, 2])
-def test_persistent_row_inverse_multi_tile(amd, mode, ny):
-    """ny = 4096 fp32 takes the persistent pipelined inverse row kernel (k_row_inv_pow2p); with
-    3 bands x 1024 rows every workgroup walks several row tiles and crosses band boundaries.
-    mode 0: no inner products, 1: <x, out>, <out, out>, 2: + <w, out> (pfb_psfconv_apply_dots,
-    the call the fused PCG makes)."""
+def test_persistent_row_kernels_multi_tile(amd, mode, ny, with_beam):
+    """ny = 4096 / 2048 fp32 take the persistent pipelined row kernels (k_row_fwd_pow2p for ny = 4096,
+    k_row_inv_pow2p for both; with and without a beam); with 3 bands every workgroup walks several row
+    tiles and crosses band boundaries.  mode 0: no inner products, 1: <x, out>, <out, out>, 2: + <w, out>
+    (pfb_psfconv_apply_dots, the call the fused PCG makes)."""
     from pfb_clean_amd import _lib, _dev
     rng = np.random.default_rng(21)
     nb, nx = 3, (1024 if ny == 4096 else 4096)      # 768 / 1536 row tiles on 256 workgroups
@@ -154,18 +155,21 @@ def test_persistent_row_inverse_multi_tile(amd, mode, ny):
     psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
     x = rng.standard_normal((nb, nx, ny)).astype(np.float32)
     w = rng.standard_normal((nb, nx, ny)).astype(np.float32)
+    beam = (0.5 + rng.random((nb, nx, ny))).astype(np.float32) if with_beam else None
     xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
-    ref = ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, x.astype(np.float64), sigmainv=0.3, wsum=1.7)
+    ref = ofc.hessian_psf_cube(xpad, xhat, xout, None if beam is None else beam.astype(np.float64), psfhat, Q,
+                               x.astype(np.float64), sigmainv=0.3, wsum=1.7)
     dev = torch.device('cuda')
     plan = amd.psf.PsfConvPlan(torch.from_numpy(psfhat.astype(np.complex64)).to(dev), nx, ny, Q)
     xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    bt = None if beam is None else torch.from_numpy(beam).to(dev)
     out = torch.empty_like(xt)
     dots = torch.zeros(3, dtype=torch.float64, device=dev)
     lib = _lib.load()
     if mode == 0:
-        plan.apply(xt, out=out, wsum=1.7, sigmainv=0.3)
+        plan.apply(xt, out=out, beam=bt, wsum=1.7, sigmainv=0.3)
     else:
-        _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(xt), None, 1.7, 0.3, _dev.ptr(out),
+        _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(xt), _dev.ptr(bt), 1.7, 0.3, _dev.ptr(out),
                                               _dev.ptr(xt), _dev.ptr(wt) if mode == 2 else None,
                                               _dev.ptr(dots), _dev.stream()))
     o = out.cpu().numpy().astype(np.float64)
