@@ -302,3 +302,45 @@ def test_psi_batched_and_fused_kernels_match_per_basis_kernels(amd, rdt, monkeyp
         assert torch.equal(a0, a1)
         tol = 1e-14 if rdt == np.float64 else 1e-6
         assert (y0 - y1).abs().max().item() <= tol * y0.abs().max().item()
+
+
+# ---- the reference's own prox tests (tests/test_psi_operator.py:50-148), same statements on the GPU
+@pmp("prox", ['prox_21', 'prox_21m'])
+@pmp("nx,ny", [(120, 64), (240, 150)])
+@pmp("nband", [1, 3])
+@pmp("nlevels", [1, 2])
+def test_prox_with_zero_step_is_the_identity(amd, prox, nx, ny, nband, nlevels):
+    """test_prox21 / test_prox21m: dot -> prox(., 0, w) -> hdot gives nbasis * x (decimal = 12)."""
+    rng = np.random.default_rng(420)
+    image = rng.standard_normal((nx, ny))
+    nu = 1.0 + 0.1 * np.arange(nband)
+    x = image[None] * nu[:, None, None] ** (-0.7)
+    bases = ['self', 'db1', 'db2', 'db3', 'db4', 'db5']
+    nbasis = len(bases)
+    psi = amd.Psi(nband, nx, ny, bases, nlevels, 1)
+    w21 = rng.random((nbasis, psi.Nymax, psi.Nxmax))
+    alpha = np.zeros((nband, nbasis, psi.Nymax, psi.Nxmax))
+    xrec = np.zeros((nband, nx, ny))
+    psi.dot(x, alpha)
+    y = (amd.p21.prox_21 if prox == 'prox_21' else amd.p21m.prox_21m)(alpha, 0.0, w21)
+    psi.hdot(y, xrec)
+    np.testing.assert_array_almost_equal(nbasis * x, xrec, decimal=12)
+
+
+@pmp("nymax,nxmax", [(1234, 134), (240, 896)])
+@pmp("nbasis", [1, 5])
+@pmp("nband", [1, 6])
+@pmp("lam,sigma", [(1.0, 75.0), (1e-1, 1.0), (1e-3, 1e-3)])
+def test_prox21m_numba_matches_prox21m(amd, nband, nbasis, nymax, nxmax, lam, sigma):
+    """test_prox21m_numba: the in-place kernel equals prox_21m even when the output holds random
+    numbers initially, also with the sigma scaling."""
+    rng = np.random.default_rng(420)
+    v = rng.standard_normal((nband, nbasis, nymax, nxmax))
+    vout = rng.standard_normal((nband, nbasis, nymax, nxmax))
+    w = rng.random((nbasis, nymax, nxmax))
+    res = amd.p21m.prox_21m(v, lam, weight=w)
+    amd.p21m.prox_21m_numba(v, vout, lam, weight=w)
+    np.testing.assert_array_almost_equal(res, vout, decimal=12)
+    res = amd.p21m.prox_21m(v / sigma, lam / sigma, weight=w)
+    amd.p21m.prox_21m_numba(v, vout, lam, sigma=sigma, weight=w)
+    np.testing.assert_array_almost_equal(res, vout, decimal=8)
