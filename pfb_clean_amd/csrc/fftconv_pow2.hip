@@ -770,8 +770,12 @@ template <typename T, int L, int E>
 struct InvP {
     using C = RowCfg<T, L, true>;
     using F = RegFft<T, L, E, C::WAVE, 0, true>;
-    // always a full 1024-thread workgroup: 4 rows at L = 2048, 8 rows (128-byte pieces) at L = 1024
-    static constexpr int G = 1024 / F::TPB;
+    // fp32: always a full 1024-thread workgroup: 4 rows at L = 2048, 8 rows (128-byte pieces) at L = 1024.
+    // fp64: two rows = 512 threads (the exchange buffers of four complex128 rows alone fill the LDS): with
+    // one such workgroup per CU every thread may use 256 VGPRs, so the even-bin result stays in registers
+    // (PARK = false) and the prefetched pieces / operands fit as well.
+    static constexpr bool PARK = sizeof(T) == 4;
+    static constexpr int G = (sizeof(T) == 4 ? 1024 : 512) / F::TPB;
     static constexpr int NT = G * F::TPB;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
@@ -781,8 +785,9 @@ struct InvP {
     static constexpr int NITE = (NBE + BSTEP - 1) / BSTEP;
     static constexpr int NITO = (NBO + BSTEP - 1) / BSTEP;
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
-    static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (size_t)G * L);
-    static constexpr bool OK = LDS <= (size_t)160 * 1024 && NT == 1024 && G >= 4 && G <= 16 && !C::WAVE;
+    static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
+    static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE &&
+                               (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && G == 2 && L >= 2048));
 };
 
 template <typename T, int L, int E, int PAR>
@@ -856,13 +861,14 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     if (vb >= ntiles) return;
     for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptw[k];
     for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
-    const bool pairing = (G * (int)sizeof(cplx<T>) * P::NVB < 128) && (tiles_per_band & 15) == 0;
+    constexpr int SH = 128 / (G * (int)sizeof(cplx<T>) * P::NVB) > 1 ? 128 / (G * (int)sizeof(cplx<T>) * P::NVB) : 1;
+    const bool pairing = SH > 1 && (tiles_per_band % (8 * SH)) == 0;
     auto tile = [&](int v, int& bl, int& i0) {
         bl = v / tiles_per_band;
         int rg = v - bl * tiles_per_band;
-        if (pairing) {                      // see k_row_inv_pow2: blocks b, b+8 share an XCD's L2
-            const int q = rg >> 4, rem = rg & 15;
-            rg = 2 * (q * 8 + (rem & 7)) + (rem >> 3);
+        if (pairing) {                      // see k_row_inv_pow2: blocks b, b+8, .. share an XCD's L2: give
+            const int q = rg / (8 * SH), rem = rg % (8 * SH);       // THEM the SH pieces of one 128-byte line
+            rg = SH * (q * 8 + (rem & 7)) + (rem >> 3);
         }
         i0 = rg * G;
     };
@@ -876,7 +882,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
-        cplx<T> vv[E];
+        cplx<T> vv[E], ev[P::PARK ? 1 : E];
         // ---- even bins
         {
             const int tid = launder((int)threadIdx.x);
@@ -889,7 +895,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             inv_build<T, L, E, 0>(lds, ltm, wq1, t, vv);
             F::template run<true>(vv, lds, t, ltw);
 #pragma unroll
-            for (int j = 0; j < E; ++j) park[j * NT + tid] = vv[j];
+            for (int j = 0; j < E; ++j) {
+                if constexpr (P::PARK) park[j * NT + tid] = vv[j]; else ev[j] = vv[j];
+            }
         }
         // ---- odd bins
         V2 xq[E], rq[E], bq[BEAM ? E : 1];
@@ -925,7 +933,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const cplx<T> zz = park[j * NT + tid] + mulc(vv[j], ltm[t + TPB * j]);
+                cplx<T> e0;
+                if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
+                const cplx<T> zz = e0 + mulc(vv[j], ltm[t + TPB * j]);
                 V2 val;
                 const V2 xx = xq[j];
                 if constexpr (BEAM) {

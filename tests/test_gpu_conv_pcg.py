@@ -182,6 +182,38 @@ def test_persistent_row_kernels_multi_tile(amd, mode, ny, with_beam):
             assert abs(d[1] - np.vdot(w.astype(np.float64), o)) < 1e-9 * np.vdot(o, o) ** 0.5 * np.linalg.norm(w)
 
 
+@pmp('with_beam', [False, True])
+def test_persistent_row_inverse_fp64_multi_tile(amd, with_beam):
+    """fp64 at ny = 4096: two-row tiles, 512-thread workgroups, even-bin result kept in registers,
+    32-byte pieces XCD-grouped four to a line (k_row_inv_pow2p<double>); 8 tiles per workgroup, all
+    three inner products."""
+    from pfb_clean_amd import _lib, _dev
+    rng = np.random.default_rng(5)
+    nb, nx, ny = 2, 2048, 4096
+    P, Q = 2 * nx, 2 * ny
+    psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
+    x = rng.standard_normal((nb, nx, ny))
+    w = rng.standard_normal((nb, nx, ny))
+    beam = 0.5 + rng.random((nb, nx, ny)) if with_beam else None
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref = ofc.hessian_psf_cube(xpad, xhat, xout, beam, psfhat, Q, x, sigmainv=0.3, wsum=1.7)
+    dev = torch.device('cuda')
+    plan = amd.psf.PsfConvPlan(torch.from_numpy(psfhat).to(dev), nx, ny, Q)
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    bt = None if beam is None else torch.from_numpy(beam).to(dev)
+    out = torch.empty_like(xt)
+    dots = torch.zeros(3, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(xt), _dev.ptr(bt), 1.7, 0.3, _dev.ptr(out),
+                                          _dev.ptr(xt), _dev.ptr(wt), _dev.ptr(dots), _dev.stream()))
+    o = out.cpu().numpy()
+    assert relerr(o, ref) < 1e-12
+    d = dots.cpu().numpy()
+    assert abs(d[0] - np.vdot(x, o)) < 1e-12 * np.linalg.norm(x) * np.linalg.norm(o)
+    assert abs(d[1] - np.vdot(w, o)) < 1e-12 * np.linalg.norm(w) * np.linalg.norm(o)
+    assert abs(d[2] - np.vdot(o, o)) < 1e-12 * np.vdot(o, o)
+
+
 @pmp('rdt', [np.float64, np.float32])
 def test_fast_path_equals_generic_path(amd, rdt, monkeypatch):
     """Same plan sizes through both kernel families (PFB_FORCE_GENERIC picks the coverage
