@@ -787,7 +787,7 @@ struct InvP {
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE &&
-                               (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && G == 2 && L >= 2048));
+                               (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && (G == 2 || G == 4) && L >= 1024));
 };
 
 template <typename T, int L, int E, int PAR>
