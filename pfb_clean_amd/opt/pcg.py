@@ -43,6 +43,35 @@ class DivPrecond:
         return x / self.div
 
 
+def _detect_div_precond(M, b):
+    """The workers write the preconditioner as a closure, `lambda x: x / sigmainv` (pcg.py:264-267,
+    fluxmop.py).  A closure cannot be inspected, but it can be ASKED: M is applied once to b itself and
+    to -2 b; if both answers are b / c and -2 b / c for one scalar c (elementwise, to rounding), M is the
+    scalar division and the solve stays on the fused path.  Anything else (a diagonal with varying
+    entries, an operator, something non-linear) fails the elementwise test and keeps the generic path."""
+    try:
+        bd = _dev.to_dev(b)
+        host = (lambda t: t.cpu().numpy()) if _dev.is_numpy(b) else (lambda t: t)
+        y1 = _dev.to_dev(M(host(bd)), bd.dtype)
+        if y1.shape != bd.shape:
+            return None
+        flat_b, flat_y = bd.reshape(-1), y1.reshape(-1)
+        k = int(torch.argmax(flat_b.abs()).item())
+        if flat_b[k].item() == 0.0 or flat_y[k].item() == 0.0:
+            return None
+        c = flat_b[k].item() / flat_y[k].item()
+        eps = 16 * torch.finfo(bd.dtype).eps
+        scale = flat_b.abs().max().item() / abs(c)
+        if (flat_y - flat_b / c).abs().max().item() > eps * scale:
+            return None
+        y2 = _dev.to_dev(M(host(-2.0 * bd)), bd.dtype).reshape(-1)
+        if (y2 + 2.0 * flat_b / c).abs().max().item() > 2 * eps * scale:
+            return None
+        return DivPrecond(c)
+    except Exception:
+        return None
+
+
 def _log(msg, verbosity, level=1):
     if verbosity >= level:
         print(msg, file=sys.stderr)
@@ -168,6 +197,8 @@ def pcg(A, b, x0=None, M=None, tol=1e-5, maxit=500, minit=100, verbosity=1,
         report_freq=10, backtrack=True, return_resid=False):
     """pfb/opt/pcg.py:53-136."""
     H = _as_hessian(A, b)
+    if H is not None and M is not None and not isinstance(M, DivPrecond):
+        M = _detect_div_precond(M, b) or M
     fusable_M = M is None or isinstance(M, DivPrecond)
     as_numpy = _dev.is_numpy(b)
     if H is not None and fusable_M:

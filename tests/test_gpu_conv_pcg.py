@@ -516,3 +516,32 @@ def test_per_band_solves_from_concurrent_host_threads(amd, golden):
             t.join()
         for k in range(nband):
             assert torch.equal(out[k], seq[k]), k
+
+
+def test_closure_preconditioner_is_recognised(amd, golden):
+    """fluxmop / _pcg_psf_impl pass `M = lambda x: x / sigmainv` (pcg.py:264-267): it is probed and kept on the
+    fused path (same iterates as DivPrecond); a diagonal with varying entries and a nonlinear M are not."""
+    from pfb_clean_amd.opt import pcg as P
+    g = golden('pcg')
+    psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    A = partial(amd.hessian.hessian_psf_cube, None, None, None, beam, psfhat, Q, sigmainv=sigmainv, wsum=1.0)
+    rhs = beam * b
+    calls = []
+    orig = P.pcg_fused
+
+    def spy(*a, **k):
+        calls.append(k.get('mdiv'))
+        return orig(*a, **k)
+    P.pcg_fused = spy
+    try:
+        x_ref = amd.pcg.pcg(A, rhs, None, M=amd.pcg.DivPrecond(sigmainv), tol=0.0, maxit=9, minit=9, verbosity=0)
+        x_lam = amd.pcg.pcg(A, rhs, None, M=lambda v: v / sigmainv, tol=0.0, maxit=9, minit=9, verbosity=0)
+        assert len(calls) == 2 and abs(calls[1] - sigmainv) < 1e-12 * sigmainv
+        assert relerr(x_lam, x_ref) < 1e-12
+        w = 1.0 + np.arange(rhs.size).reshape(rhs.shape) % 3
+        amd.pcg.pcg(A, rhs, None, M=lambda v: v / w, tol=0.0, maxit=3, minit=3, verbosity=0)
+        amd.pcg.pcg(A, rhs, None, M=lambda v: np.sign(v) * np.abs(v) ** 0.9, tol=0.0, maxit=3, minit=3, verbosity=0)
+        assert len(calls) == 2                                  # both went the generic way
+    finally:
+        P.pcg_fused = orig
