@@ -10,9 +10,10 @@ Test infrastructure (see oracle/__init__.py).  Follows
   pfb/utils/misc.py:1070-1080      l1reweight_func
   pfb/opt/pcg.py:363-420           pcg_dist (per-band variant, disabled in the live workers)
   pfb/opt/pcg.py:139-239           cg_dct (CG over a nested dict of images, unused by the live workers)
-  pfb/utils/misc.py:664-739        dds2cubes (cube assembly; PARITY UNPINNED: its module imports ~20
-                                   absent packages and builds dask graphs, so no golden vector could be
-                                   generated -- restated from the source text)
+  pfb/utils/misc.py:664-739        dds2cubes (cube assembly)
+  pfb/utils/misc.py:1366-1423      freqmul, setup_parametrisation
+All of misc.py's functions here are pinned by tests/golden/misc.npz, produced by the reference's real
+module (tests/golden/_refstubs.py:load_misc).
 
 The recurrences are written out in full so the
 semantics that matter for parity are visible: residual sign r = A x - b, the
@@ -89,6 +90,34 @@ def l1reweight_func(psiH, outvar, rmsfactor, rms_comps, model, alpha=4):
     psiH(model, outvar)
     mcomps = np.abs(np.sum(outvar, axis=0))
     return (1 + rmsfactor) / (1 + mcomps ** alpha / rms_comps ** alpha)
+
+
+def freqmul(A, x):
+    """misc.py:1366-1375: out[k] = sum_l A[k, l] x[l] over an (nband, nx, ny) cube."""
+    return np.einsum('kl,lij->kij', A, x)
+
+
+def setup_parametrisation(mode='id', minval=1e-5, sigma=1.0, freq=None, lscale=1.0):
+    """misc.py:1378-1423: x = f(s), K = sigma^2 exp(-(nu_i - nu_j)^2 / (2 lscale^2)) = L L^T over the
+    normalised band frequencies; returns (func, finv, dfunc, dhfunc)."""
+    from scipy.linalg import solve_triangular
+    nu = freq / np.mean(freq)
+    nband = nu.size
+    K = sigma ** 2 * np.exp(-(nu[:, None] - nu[None, :]) ** 2 / (2 * lscale ** 2))
+    L = np.linalg.cholesky(K + 1e-10 * np.eye(nband))
+    LH = L.T
+
+    def solve(x):
+        return solve_triangular(L, x.reshape(nband, -1), lower=True).reshape(x.shape)
+    if mode == 'id':
+        return ((lambda x: freqmul(L, x)), solve,
+                (lambda x0, v: freqmul(L, v)), (lambda x0, v: freqmul(LH, v)))
+    if mode == 'exp':
+        return ((lambda x: np.exp(freqmul(L, x))),
+                (lambda x: np.log(np.maximum(np.abs(solve(x)), minval))),
+                (lambda x0, v: np.exp(freqmul(L, x0)) * freqmul(L, v)),
+                (lambda x0, v: freqmul(LH, v * np.exp(freqmul(L, x0)))))
+    raise ValueError(f"Unknown mode - {mode}")
 
 
 # ---------------------------------------------------------------------- pcg

@@ -9,7 +9,10 @@ substituted; every line of pfb/ that runs is the reference's own.
   ducc0.misc       -> make_noncritical = identity
   pywt             -> Wavelet(name).filter_bank from oracle.daubechies (exact tables)
   numexpr.evaluate -> eval in the caller's frame, honouring out=
-  pfb.utils.misc   -> norm_diff restated (the real module needs ~20 absent packages)
+  numba.extending.overload -> calls the generator with the arguments and runs what it returns
+  dask / dask.array -> zeros / stack / compute on numpy (eager), for misc.py's dds2cubes
+  daskms, omegaconf, skimage, africanus, xarray, quartical, jax -> inert placeholders (misc.py
+                      imports them at module level; nothing exercised here calls them)
 
 Used by tests/golden/make_golden.py ONLY, in the build container ONLY
 (/root/reference does not exist on the GPU box).
@@ -105,15 +108,6 @@ class _Log:
         pass
 
 
-def _norm_diff(x, xp):
-    # pfb/utils/misc.py:1326-1351
-    if x.ndim not in (2, 3):
-        raise ValueError("norm_diff is only implemented for 2D or 3D arrays")
-    num = float(np.sum((x.astype(np.float64) - xp.astype(np.float64)) ** 2))
-    den = 1e-12 + float(np.sum(x.astype(np.float64) ** 2))
-    return np.sqrt(num / den)
-
-
 def install(repo_root):
     """Insert the stub modules, then make /root/reference importable."""
     sys.path.insert(0, repo_root)
@@ -157,5 +151,58 @@ def install(repo_root):
     sys.path.insert(0, '/root/reference')
     import pfb  # noqa: F401  (no import-time side effects, pfb/__init__.py:33-137)
     pu = _mod('pfb.utils')
-    # give_edges: imported by deconv/hogbom.py:3 but never called there
-    pu.misc = _mod('pfb.utils.misc', norm_diff=_norm_diff, give_edges=None)
+    # the reference's real misc.py (norm_diff for pcg / primal_dual, give_edges for hogbom's import)
+    pu.misc = load_misc()
+    sys.modules['pfb.utils.misc'] = pu.misc
+
+
+class _AnyModule(types.ModuleType):
+    """Module whose every attribute is an inert placeholder (names imported by misc.py that the
+    functions exercised here never touch: daskms readers, skimage.label, jax, ...)."""
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Any()
+
+
+def _overload(target, **kw):
+    """numba.extending.overload stand-in: numba would compile gen(*types)(*args); here the generator
+    is called with the arguments themselves (numpy arrays carry .ndim like the numba types do) and the
+    implementation it returns is run as plain Python -- every line executed is the reference's."""
+    def deco(gen):
+        def dispatch(*args):
+            return gen(*args)(*args)
+        target.__globals__[target.__name__] = dispatch
+        return gen
+    return deco
+
+
+def load_misc():
+    """Load the reference's REAL pfb/utils/misc.py (as module 'pfb_ref_misc'; install() registers it as
+    pfb.utils.misc) for norm_diff, l1reweight_func, dds2cubes, freqmul and setup_parametrisation.  Its ~20 absent third-party imports become inert placeholders, except
+    dask / dask.array, which dds2cubes really uses: zeros / stack / compute map onto numpy (eager
+    evaluation of the same graph)."""
+    import importlib.util
+    sys.modules['numba.extending'].overload = _overload
+    sys.modules['numba'].jit = _identity_decorator
+    sys.modules['ducc0.fft'].good_size = lambda n, real=False: sfft.next_fast_len(n, real=real)
+
+    dk = sys.modules['dask']
+    dk.compute = lambda *a, **k: tuple(a)
+    da = sys.modules['dask.array']
+    da.zeros = lambda shape, chunks=None, dtype=float: np.zeros(shape, dtype=dtype)
+    da.stack = lambda seq, axis=0: np.stack(list(seq), axis=axis)
+    for name in ('dask.distributed', 'dask.diagnostics', 'daskms', 'daskms.experimental',
+                 'daskms.experimental.zarr', 'omegaconf', 'skimage', 'skimage.morphology',
+                 'africanus', 'africanus.coordinates', 'africanus.coordinates.coordinates',
+                 'xarray', 'quartical', 'quartical.utils', 'quartical.utils.dask',
+                 'jax', 'jax.numpy'):
+        if name not in sys.modules:
+            sys.modules[name] = _AnyModule(name)
+    spec = importlib.util.spec_from_file_location('pfb_ref_misc',
+                                                  '/root/reference/pfb/utils/misc.py')
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules['pfb_ref_misc'] = mod
+    spec.loader.exec_module(mod)
+    return mod

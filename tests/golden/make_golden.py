@@ -426,7 +426,94 @@ def gen_clark():
     print('clark.npz', len(out))
 
 
+class _RefVar:
+    """xarray.DataArray stand-in: what dds2cubes touches (misc.py:665-713)."""
+
+    def __init__(self, a):
+        self.data = self.values = a
+        self.dtype, self.shape = a.dtype, a.shape
+
+
+class _RefDS(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def gen_misc():
+    """The real pfb/utils/misc.py (loaded by _refstubs.load_misc): norm_diff (:1316-1351),
+    l1reweight_func (:1070-1080), dds2cubes (:664-739), freqmul and setup_parametrisation
+    (:1366-1423)."""
+    misc = _refstubs.load_misc()
+    out = {}
+    rng = np.random.default_rng(470)
+    # norm_diff, 3-D and 2-D, both precisions
+    for tag, dt in (('f64', np.float64), ('f32', np.float32)):
+        x = rng.standard_normal((3, 10, 12)).astype(dt)
+        xp = (x + 0.1 * rng.standard_normal(x.shape)).astype(dt)
+        out[f'nd_{tag}_x'], out[f'nd_{tag}_xp'] = x, xp
+        out[f'nd_{tag}_3d'] = np.float64(misc.norm_diff(x, xp))
+        out[f'nd_{tag}_2d'] = np.float64(misc.norm_diff(x[1], xp[1]))
+    out['nd_zero'] = np.float64(misc.norm_diff(np.zeros((4, 4)), np.zeros((4, 4))))
+    # l1reweight_func through the reference's own Psi.dot
+    nband, nx, ny, bases, nlevel = 2, 32, 24, ['self', 'db1', 'db3'], 2
+    psi = Psi(nband, nx, ny, bases, nlevel, 1)
+    model = rng.standard_normal((nband, nx, ny))
+    model[np.abs(model) < 0.8] = 0.0
+    outvar = np.zeros((nband, psi.nbasis, psi.Nymax, psi.Nxmax))
+    rms_comps = 0.2 + rng.random((psi.nbasis, psi.Nymax, psi.Nxmax))
+    out['rw_model'], out['rw_rms'] = model, rms_comps
+    out['rw_meta'] = np.array([nband, nx, ny, nlevel])
+    out['rw_bases'] = np.array(bases)
+    for alpha in (4, 2):
+        out[f'rw_a{alpha}'] = misc.l1reweight_func(psi.dot, outvar, 1.5, rms_comps, model, alpha=alpha)
+    # dds2cubes: two datasets share band 0, one in band 1, band 2 stays empty
+    nb, dx, dy = 3, 12, 10
+    P, Q = 2 * dx, 2 * dy
+    ins = {}
+    for i, (bandid, w) in enumerate(((0, 2.0), (1, 3.5), (0, 1.5))):
+        ins[i] = dict(DIRTY=rng.standard_normal((dx, dy)), BEAM=0.5 + rng.random((dx, dy)),
+                      WSUM=np.array([w]), PSF=rng.standard_normal((P, Q)),
+                      PSFHAT=rng.standard_normal((P, Q // 2 + 1)) + 1j * rng.standard_normal((P, Q // 2 + 1)),
+                      MODEL=rng.standard_normal((dx, dy)), RESIDUAL=rng.standard_normal((dx, dy)),
+                      DUAL=rng.standard_normal((2, 14, 13)), bandid=bandid)
+        for k, v in ins[i].items():
+            out[f'dds{i}_{k}'] = np.asarray(v)
+
+    def build(skip=()):
+        return [_RefDS({k: (_RefVar(v.copy()) if k != 'bandid' else v) for k, v in ins[i].items()
+                        if k not in skip}) for i in range(3)]
+    names = ('dirty', 'model', 'residual', 'psf', 'psfhat', 'mean_beam', 'wsums', 'dual')
+    for tag, kw, skip in (('beam', dict(apparent=False), ()), ('app', dict(apparent=True), ()),
+                          ('bare', dict(apparent=False), ('RESIDUAL', 'DUAL', 'PSF', 'PSFHAT')),
+                          ('nodual', dict(apparent=False, dual=False), ())):
+        res = misc.dds2cubes(build(skip), nb, **kw)
+        for n, r in zip(names, res):
+            if r is not None:
+                out[f'cubes_{tag}_{n}'] = np.asarray(r)
+    # freqmul + setup_parametrisation
+    A = rng.standard_normal((4, 4))
+    x = rng.standard_normal((4, 9, 7))
+    out['fm_A'], out['fm_x'], out['fm_out'] = A, x, misc.freqmul(A, x)
+    freq = np.linspace(0.9e9, 1.7e9, 4)
+    out['par_freq'] = freq
+    x0 = 0.3 * rng.standard_normal((4, 9, 7))
+    v = rng.standard_normal((4, 9, 7))
+    out['par_x0'], out['par_v'] = x0, v
+    for mode in ('id', 'exp'):
+        func, finv, dfunc, dhfunc = misc.setup_parametrisation(mode=mode, minval=1e-5, sigma=0.8,
+                                                               freq=freq, lscale=0.5)
+        out[f'par_{mode}_func'] = func(x0)
+        out[f'par_{mode}_finv'] = finv(func(x0))
+        out[f'par_{mode}_dfunc'] = dfunc(x0, v)
+        out[f'par_{mode}_dhfunc'] = dhfunc(x0, v)
+    np.savez_compressed(os.path.join(HERE, 'misc.npz'), **out)
+    print('misc.npz', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark', 'misc']
     for w in which:
         globals()['gen_' + w]()

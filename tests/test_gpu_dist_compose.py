@@ -259,7 +259,7 @@ def test_hessian_psf_slice_class_and_pcg_dist(tag):
 @pytest.mark.parametrize('apparent', [False, True])
 def test_dds2cubes_device_loader(apparent):
     """device-resident cube assembly (misc.py:664-739) against the oracle restatement
-    (parity unpinned by a reference fixture, see oracle/solvers.py)."""
+    (the reference's own outputs: test_dds2cubes_against_reference_vectors)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pfb_clean_amd.utils.misc import dds2cubes
@@ -456,8 +456,8 @@ def test_clark_minor_cycle(rdt):
 
 @pytest.mark.parametrize('rdt', [np.float64, np.float32])
 def test_freqmul_and_parametrisations(rdt):
-    """misc.py:1366-1423 (freqmul, setup_parametrisation) against numpy; parity unpinned by a reference
-    fixture (the module cannot be imported here), the functions are 10 lines of arithmetic."""
+    """misc.py:1366-1423 (freqmul, setup_parametrisation) against numpy in both precisions (the
+    reference's own outputs: test_freqmul_parametrisation_against_reference_vectors)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pfb_clean_amd.utils.misc import freqmul, setup_parametrisation
@@ -573,3 +573,82 @@ def test_new_entry_points_reject_bad_arguments():
     x = torch.zeros((2, 4, 4), dtype=torch.float64, device=dev)
     A = torch.eye(2, dtype=torch.float64, device=dev)
     assert lib.pfb_freqmul(1, _dev.ptr(A), _dev.ptr(x), _dev.ptr(x), 2, 16, None, None, _dev.stream()) == -1   # aliasing
+
+
+# ------------------------------------------------ pfb/utils/misc.py against tests/golden/misc.npz
+def _misc():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'misc.npz'))
+
+
+def test_norm_diff_against_reference_vectors():
+    """misc.py:1316-1351: the device reduction against the values the reference's loop gives."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import norm_diff
+    g = _misc()
+    for tag, rtol in (('f64', 1e-13), ('f32', 1e-6)):
+        x, xp = g[f'nd_{tag}_x'], g[f'nd_{tag}_xp']
+        for a, b, key in ((x, xp, '3d'), (x[1], xp[1], '2d')):
+            want = float(g[f'nd_{tag}_{key}'])
+            assert abs(norm_diff(a, b) - want) <= rtol * want
+            assert abs(norm_diff(torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()) - want) <= rtol * want
+    assert norm_diff(np.zeros((4, 4)), np.zeros((4, 4))) == 0.0
+
+
+@pytest.mark.parametrize('kind', ['numpy', 'tensor'])
+def test_l1reweight_against_reference_vectors(kind):
+    """misc.py:1070-1080 with the device Psi.dot as psiH."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import l1reweight_func
+    from pfb_clean_amd.operators.psi import Psi
+    g = _misc()
+    nband, nx, ny, nlevel = (int(v) for v in g['rw_meta'])
+    psi = Psi(nband, nx, ny, [str(b) for b in g['rw_bases']], nlevel)
+    wrap = (lambda a: torch.from_numpy(np.array(a)).cuda()) if kind == 'tensor' else (lambda a: np.array(a))
+    outvar = wrap(np.zeros((nband, psi.nbasis, psi.Nymax, psi.Nxmax)))
+    for alpha in (4, 2):
+        got = l1reweight_func(psi.dot, outvar, 1.5, wrap(g['rw_rms']), wrap(g['rw_model']), alpha=alpha)
+        got = got.cpu().numpy() if kind == 'tensor' else got
+        assert np.abs(got - g[f'rw_a{alpha}']).max() < 1e-10
+
+
+@pytest.mark.parametrize('kind', ['numpy', 'tensor'])
+def test_dds2cubes_against_reference_vectors(kind):
+    """misc.py:664-739: all four call shapes of the fixture (beam-weighted, apparent, no
+    residual/psf/dual variables, dual=False)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import dds2cubes
+    from test_oracle_golden import misc_dds, CUBE_NAMES, CUBE_CASES
+    g = _misc()
+    wrap = (lambda a: torch.from_numpy(a).cuda()) if kind == 'tensor' else (lambda a: a)
+    for tag, kw, skip in CUBE_CASES:
+        got = dds2cubes(misc_dds(g, wrap=wrap, skip=skip), 3, **kw)
+        for n, r in zip(CUBE_NAMES, got):
+            key = f'cubes_{tag}_{n}'
+            if key in g.files:
+                assert r.is_cuda and tuple(r.shape) == g[key].shape
+                assert np.abs(r.cpu().numpy() - g[key]).max() <= 1e-14 * max(1.0, np.abs(g[key]).max())
+            else:
+                assert r is None
+
+
+def test_freqmul_parametrisation_against_reference_vectors():
+    """misc.py:1366-1423: pfb_freqmul and the four closures of both parametrisations."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.utils.misc import freqmul, setup_parametrisation
+    g = _misc()
+    assert np.abs(freqmul(g['fm_A'], g['fm_x']) - g['fm_out']).max() < 1e-13
+    for mode in ('id', 'exp'):
+        func, finv, dfunc, dhfunc = setup_parametrisation(mode=mode, minval=1e-5, sigma=0.8,
+                                                          freq=g['par_freq'], lscale=0.5)
+        x0, v = g['par_x0'], g['par_v']
+        for got, key, tol in ((func(x0), 'func', 1e-12), (dfunc(x0, v), 'dfunc', 1e-12),
+                              (dhfunc(x0, v), 'dhfunc', 1e-12), (finv(func(x0)), 'finv', 1e-7)):
+            want = g[f'par_{mode}_{key}']
+            assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (mode, key)
+        xt, vt = torch.from_numpy(x0).cuda(), torch.from_numpy(v).cuda()
+        got = dfunc(xt, vt)
+        assert got.is_cuda and np.abs(got.cpu().numpy() - g[f'par_{mode}_dfunc']).max() < 1e-12

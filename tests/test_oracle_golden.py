@@ -368,8 +368,8 @@ def make_dds(rng, nband=3, nx=12, ny=10, with_resid=True, with_dual=True, wrap=l
 
 @pytest.mark.parametrize('apparent', [False, True])
 def test_dds2cubes_oracle_against_definition(apparent):
-    """misc.py:664-739 (parity unpinned: no reference fixture can be generated, see
-    oracle/solvers.py) -- checked against the formulas written out by hand."""
+    """misc.py:664-739 against the formulas written out by hand (the reference's own outputs:
+    test_dds2cubes_pinned below)."""
     rng = np.random.default_rng(5)
     dds = make_dds(rng)
     dirty, model, resid, psf, psfhat, mbeam, wsums, dual = sv.dds2cubes(dds, 3, apparent=apparent)
@@ -444,3 +444,72 @@ def test_hogbom_golden(golden):
         model, status, _ = ock.hogbom(g['ID'].copy(), g['PSF'], **kw)
         assert status == int(g[f'hogbom_{tag}_status'])
         assert_allclose(model, g[f'hogbom_{tag}_model'], rtol=1e-11, atol=1e-14)
+
+
+# ------------------------------------------------------- misc.py (tests/golden/misc.npz)
+def misc_dds(g, wrap=lambda a: a, skip=()):
+    """The three datasets of golden/misc.npz as in-memory datasets (two share band 0)."""
+    dds = []
+    for i in range(3):
+        d = {k: _Var(wrap(np.array(g[f'dds{i}_{k}']))) for k in
+             ('DIRTY', 'BEAM', 'PSF', 'PSFHAT', 'MODEL', 'RESIDUAL', 'DUAL') if k not in skip}
+        d['WSUM'] = _Var(np.array(g[f'dds{i}_WSUM']))
+        dds.append(_DS(bandid=int(g[f'dds{i}_bandid']), **d))
+    return dds
+
+
+CUBE_NAMES = ('dirty', 'model', 'residual', 'psf', 'psfhat', 'mean_beam', 'wsums', 'dual')
+CUBE_CASES = (('beam', dict(apparent=False), ()), ('app', dict(apparent=True), ()),
+              ('bare', dict(apparent=False), ('RESIDUAL', 'DUAL', 'PSF', 'PSFHAT')),
+              ('nodual', dict(apparent=False, dual=False), ()))
+
+
+def test_norm_diff_pinned(golden):
+    """misc.py:1316-1351 run through the reference's own numba overload body."""
+    g = golden('misc')
+    for tag in ('f64', 'f32'):
+        x, xp = g[f'nd_{tag}_x'], g[f'nd_{tag}_xp']
+        assert_allclose(sv.norm_diff(x, xp), g[f'nd_{tag}_3d'], rtol=1e-13 if tag == 'f64' else 1e-6)
+        assert_allclose(sv.norm_diff(x[1], xp[1]), g[f'nd_{tag}_2d'], rtol=1e-13 if tag == 'f64' else 1e-6)
+    assert g['nd_zero'] == 0.0
+
+
+def test_l1reweight_pinned(golden):
+    """misc.py:1070-1080 with the reference's Psi.dot as psiH."""
+    g = golden('misc')
+    nband, nx, ny, nlevel = (int(v) for v in g['rw_meta'])
+    psi = wv.Psi(nband, nx, ny, [str(b) for b in g['rw_bases']], nlevel)
+    outvar = np.zeros((nband, psi.nbasis, psi.Nymax, psi.Nxmax))
+    for alpha in (4, 2):
+        got = sv.l1reweight_func(psi.dot, outvar, 1.5, g['rw_rms'], g['rw_model'], alpha=alpha)
+        assert_allclose(got, g[f'rw_a{alpha}'], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize('case', CUBE_CASES, ids=[c[0] for c in CUBE_CASES])
+def test_dds2cubes_pinned(golden, case):
+    """misc.py:664-739 (the reference's lines run eagerly: dask.array zeros/stack/compute mapped onto
+    numpy by tests/golden/_refstubs.py)."""
+    g = golden('misc')
+    tag, kw, skip = case
+    got = sv.dds2cubes(misc_dds(g, skip=skip), 3, **kw)
+    for n, r in zip(CUBE_NAMES, got):
+        key = f'cubes_{tag}_{n}'
+        if key in g.files:
+            assert r.shape == g[key].shape and r.dtype == g[key].dtype
+            assert_allclose(r, g[key], rtol=1e-14, atol=0)
+        else:
+            assert r is None
+
+
+def test_freqmul_parametrisation_pinned(golden):
+    """misc.py:1366-1423."""
+    g = golden('misc')
+    assert_allclose(sv.freqmul(g['fm_A'], g['fm_x']), g['fm_out'], rtol=1e-13, atol=1e-14)
+    for mode in ('id', 'exp'):
+        func, finv, dfunc, dhfunc = sv.setup_parametrisation(mode=mode, minval=1e-5, sigma=0.8,
+                                                            freq=g['par_freq'], lscale=0.5)
+        x0, v = g['par_x0'], g['par_v']
+        assert_allclose(func(x0), g[f'par_{mode}_func'], rtol=1e-12)
+        assert_allclose(finv(func(x0)), g[f'par_{mode}_finv'], rtol=1e-7, atol=1e-9)
+        assert_allclose(dfunc(x0, v), g[f'par_{mode}_dfunc'], rtol=1e-12, atol=1e-13)
+        assert_allclose(dhfunc(x0, v), g[f'par_{mode}_dhfunc'], rtol=1e-12, atol=1e-13)
