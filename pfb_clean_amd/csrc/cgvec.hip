@@ -27,10 +27,15 @@ constexpr int RED_BLOCK = 256;
 constexpr int RED_MAX_GRID = 1024;
 
 static inline int red_grid(size_t nvec) {
+    static const int cap = [] {           // PFB_RED_GRID: A/B knob for the streaming kernels' grid cap
+        const char* e = getenv("PFB_RED_GRID");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 && v <= 2048 ? v : RED_MAX_GRID;   // 4 sums x grid <= PFB_REDUCE_WS_DOUBLES
+    }();
     size_t g = (nvec + RED_BLOCK - 1) / RED_BLOCK;
     g = (g + 3) / 4;                      // >= 4 vectors per thread when large
     if (g < 1) g = 1;
-    if (g > RED_MAX_GRID) g = RED_MAX_GRID;
+    if (g > (size_t)cap) g = cap;
     return (int)g;
 }
 
@@ -248,7 +253,7 @@ k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__
 // so beta = rho(alpha)/rho is available up front (the reference forms beta from the recomputed
 // <r',y'>; the two differ by rounding only -- the recomputed value is still what the NEXT
 // iteration uses as rnorm).  sums: <r',y'>, |x'-x|^2, |x'|^2, count(p' != 0)
-template <typename T, int V>
+template <typename T, int V, int U = 1>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ p,
                  const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
@@ -257,30 +262,40 @@ k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict
     const T alpha = dead ? T(0) : (T)alpha_dev[0];
     const T beta = (T)alpha_dev[S_BETA - S_ALPHA];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (size_t)gridDim.x * blockDim.x) {
-        Pack<T, V> px = ld<T, V>(x, i), pr = ld<T, V>(r, i), pp = ld<T, V>(p, i),
-                   pa = ld<T, V>(Ap, i), ox, orr;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nvec; i0 += U * stride) {
+        Pack<T, V> px[U], pr[U], pp[U], pa[U];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const T xnew = px.e[e] + alpha * pp.e[e];
-            const T rnew = pr.e[e] + alpha * pa.e[e];
-            const T y = mdiv > T(0) ? rnew / mdiv : rnew;
-            ox.e[e] = xnew;
-            orr.e[e] = rnew;
-            const double d = (double)xnew - (double)px.e[e];
-            acc[0] += (double)rnew * (double)y;
-            acc[1] += d * d;
-            acc[2] += (double)xnew * (double)xnew;
-            if (!dead) {
-                const T pn = beta * pp.e[e] - y;
-                pp.e[e] = pn;
-            }
-            acc[3] += (pp.e[e] != T(0)) ? 1.0 : 0.0;
+        for (int u = 0; u < U; ++u) {              // all loads of the U strips in flight together
+            const size_t i = i0 + u * stride;
+            if (i < nvec) { px[u] = ld<T, V>(x, i); pr[u] = ld<T, V>(r, i); pp[u] = ld<T, V>(p, i); pa[u] = ld<T, V>(Ap, i); }
         }
-        st<T, V>(xn, i, ox);
-        st<T, V>(rn, i, orr);
-        if (!dead) st<T, V>(p, i, pp);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t i = i0 + u * stride;
+            if (i >= nvec) break;
+            Pack<T, V> ox, orr;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T xnew = px[u].e[e] + alpha * pp[u].e[e];
+                const T rnew = pr[u].e[e] + alpha * pa[u].e[e];
+                const T y = mdiv > T(0) ? rnew / mdiv : rnew;
+                ox.e[e] = xnew;
+                orr.e[e] = rnew;
+                const double d = (double)xnew - (double)px[u].e[e];
+                acc[0] += (double)rnew * (double)y;
+                acc[1] += d * d;
+                acc[2] += (double)xnew * (double)xnew;
+                if (!dead) {
+                    const T pn = beta * pp[u].e[e] - y;
+                    pp[u].e[e] = pn;
+                }
+                acc[3] += (pp[u].e[e] != T(0)) ? 1.0 : 0.0;
+            }
+            st<T, V>(xn, i, ox);
+            st<T, V>(rn, i, orr);
+            if (!dead) st<T, V>(p, i, pp[u]);
+        }
     }
     emit_partials<4>(acc, ws);
 }
@@ -434,6 +449,45 @@ static int axpby_impl(double a, const void* x, double b, void* y, size_t n, hipS
     return PFB_OK;
 }
 
+// The fused update streams 4 reads + 3 writes; measured on MI355X (tools/micro/hbm_stream.hip and
+// the bench) that mix runs fastest with ONE 256-thread workgroup per CU -- few concurrent streams
+// per HBM channel -- not with the chip oversubscribed: 256 workgroups 0.60 ms, 1024 0.78 ms at
+// 8 x 4096^2 fp32.  Returns the grid (= number of partial sums per quantity).
+static int stream_grid(size_t nvec) {
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        const char* e = getenv("PFB_UPD_GRID");        // A/B knob
+        const int o = e ? atoi(e) : 0;
+        return o > 0 && o <= 2048 ? o : v;
+    }();
+    size_t g = (nvec + RED_BLOCK - 1) / RED_BLOCK;
+    g = (g + 3) / 4;
+    if (g < 1) g = 1;
+    if (g > (size_t)ncu) g = ncu;
+    return (int)g;
+}
+template <typename T>
+static int launch_update_dir(size_t n, const T* x, const T* r, T* p, const T* Ap, T* xn, T* rn,
+                             const double* alpha_dev, T mdiv, double* ws, hipStream_t st) {
+    static const int unroll = [] { const char* e = getenv("PFB_UPD_UNROLL"); return e ? atoi(e) : 1; }();
+    using PL = std::initializer_list<const void*>;
+    constexpr int V = V16<T>::N;
+    if (can_vec<T>(n, PL{x, r, p, Ap, xn, rn})) {
+        const size_t nvec = n / V;
+        const int G = stream_grid(nvec);
+        if (unroll == 2)
+            hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
+        else
+            hipLaunchKernelGGL((k_pcg_update_dir<T, V, 1>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
+        return G;
+    }
+    const int G = stream_grid(n);
+    hipLaunchKernelGGL((k_pcg_update_dir<T, 1, 1>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, n, ws);
+    return G;
+}
+
 // ------------------------------------------------------------------------ PCG driver
 struct PcgWork {
     char* r; char* p; char* Ap; char* xalt; char* ralt;
@@ -541,9 +595,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
                 // needs <r,Ap>, <Ap,Ap> even without backtracking (beta comes from rho(alpha))
                 if (!begun)
                     hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
-                PFB_LAUNCH_VEC(T, k_pcg_update_dir, n, (PL{xcur, rcur, p, Ap, xnew, rnew}), (const T*)xcur,
-                               (const T*)rcur, p, (const T*)Ap, xnew, rnew,
-                               (const double*)(S + S_ALPHA), mdiv);
+                G_used = launch_update_dir<T>(n, xcur, rcur, p, Ap, xnew, rnew, S + S_ALPHA, mdiv, ws, st);
                 if (!allreduce) {
                     hipLaunchKernelGGL(k_final_sum_waves_end, dim3(1), dim3(256), 0, st, ws, G_used, S);
                 } else {
