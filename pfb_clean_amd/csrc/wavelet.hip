@@ -613,6 +613,54 @@ k_dual_update(const T* vp, T* __restrict__ v, const T* __restrict__ w, T lam, T 
     }
 }
 
+// Same arithmetic, 16-byte accesses, every band's vp / v held in registers between the band sum and
+// the threshold (one read of each instead of two).  NB = nband (compile time, <= 8); V = 16 / sizeof(T).
+template <typename T, int NB>
+__global__ void __launch_bounds__(256)
+k_dual_update_vec(const T* vp, T* __restrict__ v, const T* __restrict__ w, T lam, T sigma,
+                  size_t nper, T* vp_out) {              // vp_out may alias vp
+    constexpr int V = 16 / sizeof(T);
+    typedef T VT __attribute__((ext_vector_type(V)));
+    const size_t nvec = nper / V;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        VT a_vp[NB], a_v[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            a_vp[b] = reinterpret_cast<const VT*>(vp + (size_t)b * nper)[i];
+            a_v[b] = reinterpret_cast<const VT*>(v + (size_t)b * nper)[i];
+        }
+        const VT wv = reinterpret_cast<const VT*>(w)[i];
+        T fac[V];
+        bool nz[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            T sum = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) sum += a_vp[b][e] + sigma * a_v[b][e];
+            const T a = fabs(sum / sigma);
+            nz[e] = a != T(0);
+            fac[e] = 1;
+            if (nz[e]) {
+                const T soft = fmax(a - lam * wv[e] / sigma, T(0));
+                fac[e] = T(1) - soft / a;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            VT vn, vo;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const T vt = a_vp[b][e] + sigma * a_v[b][e];
+                vn[e] = nz[e] ? vt * fac[e] : vt;
+                vo[e] = T(2) * vn[e] - a_vp[b][e];
+            }
+            reinterpret_cast<VT*>(v + (size_t)b * nper)[i] = vn;
+            if (vp_out) reinterpret_cast<VT*>(vp_out + (size_t)b * nper)[i] = vo;
+        }
+    }
+}
+
 // Band-sharded dual update (bands split over GPUs): phase 1 forms the LOCAL band sum of
 // vtilde = vp + sigma v per coefficient; after an all-reduce(sum) of that plane over the
 // ranks, phase 2 applies the same soft threshold with the GLOBAL sum (prox_21m.py:95-103).
@@ -1221,11 +1269,47 @@ static int psi_hdot_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t st) {
     return PFB_OK;
 }
 
+// grid for the streaming elementwise kernels that WRITE as much as they read: a few workgroups per
+// CU (tools/micro/hbm_stream.hip: the write-heavy mixes lose 10-25 % when the chip is oversubscribed)
+static inline int stream_grid(size_t nvec, int per_cu) {
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    size_t g = (nvec + 255) / 256;
+    if (g > (size_t)ncu * per_cu) g = (size_t)ncu * per_cu;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 static inline int ew_grid(size_t n) {
     size_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+template <typename T>
+static void dual_update_launch(const T* vp, T* v, const T* w, T lam, T sigma, int nband, size_t nper, T* vp_out,
+                               hipStream_t st) {
+    constexpr int V = 16 / sizeof(T);
+    static const int per_cu = [] { const char* e = getenv("PFB_DUAL_PER_CU"); const int o = e ? atoi(e) : 0;
+                                   return o > 0 && o <= 16 ? o : 1; }();
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec = nband <= 8 && nper % V == 0 && al(vp) && al(v) && al(w) && (!vp_out || al(vp_out));
+    if (!vec) {
+        hipLaunchKernelGGL((k_dual_update<T>), dim3(ew_grid(nper)), dim3(256), 0, st, vp, v, w, lam, sigma, nband,
+                           nper, vp_out);
+        return;
+    }
+    const dim3 grid(stream_grid(nper / V, per_cu));
+#define PFB_DU_CASE(NB) case NB: hipLaunchKernelGGL((k_dual_update_vec<T, NB>), grid, dim3(256), 0, st, vp, v, w, \
+                                                    lam, sigma, nper, vp_out); break;
+    switch (nband) { PFB_DU_CASE(1) PFB_DU_CASE(2) PFB_DU_CASE(3) PFB_DU_CASE(4) PFB_DU_CASE(5) PFB_DU_CASE(6)
+                     PFB_DU_CASE(7) PFB_DU_CASE(8) }
+#undef PFB_DU_CASE
 }
 
 }  // namespace pfb
@@ -1351,12 +1435,10 @@ int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight, doub
                     int nband, size_t nper, void* vp_out, void* stream) {
     PFB_REQUIRE(vp && v && weight && nband > 0, PFB_ERR_INVALID, "dual_update: bad argument");
     hipStream_t st = as_stream(stream);
-    if (dtype == PFB_F32)
-        hipLaunchKernelGGL((k_dual_update<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
-                           (float*)v, (const float*)weight, (float)lam, (float)sigma, nband, nper, (float*)vp_out);
-    else
-        hipLaunchKernelGGL((k_dual_update<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
-                           (double*)v, (const double*)weight, lam, sigma, nband, nper, (double*)vp_out);
+    if (dtype == PFB_F32) dual_update_launch<float>((const float*)vp, (float*)v, (const float*)weight, (float)lam,
+                                                    (float)sigma, nband, nper, (float*)vp_out, st);
+    else dual_update_launch<double>((const double*)vp, (double*)v, (const double*)weight, lam, sigma, nband, nper,
+                                    (double*)vp_out, st);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
