@@ -372,6 +372,39 @@ __global__ void k_iter_end_begin(double* S, double mdiv, int predict) {
     iter_end_dev(S, 1);
     iter_begin_dev(S, mdiv, predict);
 }
+// One launch per iteration for every scalar the sync-free driver needs: the three fused dots of the
+// convolution (per-workgroup partials `cp`), the four sums the
+// previous iteration's fused update left in `ws` (when `have_upd`), then -- unless an all-reduce has
+// to come first (`logic` == 0) -- the end of that iteration and the begin of this one.
+__global__ void __launch_bounds__(256)
+k_iter_sums(const double* __restrict__ cp, int ncp, const double* __restrict__ ws, int G, int have_upd,
+            double* __restrict__ S, double mdiv, int predict, int logic) {
+    __shared__ double vals[8];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // seven independent sums, each by ONE wave in a fixed lane-strided order (deterministic):
+    // wave w takes conv quantity w (w < 3) and update quantity w
+    if (w < 3) {
+        double acc = 0.0;
+        for (int k = lane; k < ncp; k += 64) acc += cp[(size_t)w * ncp + k];
+        acc = wave_sum(acc);
+        if (lane == 0) vals[w] = acc;
+    }
+    if (have_upd) {
+        double acc = 0.0;
+        for (int g = lane; g < G; g += 64) acc += ws[(size_t)w * G + g];
+        acc = wave_sum(acc);
+        if (lane == 0) vals[3 + w] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S[S_PAP] = vals[0]; S[S_RAP] = vals[1]; S[S_APAP] = vals[2];
+        if (have_upd) { S[S_RHON] = vals[3]; S[S_NUM] = vals[4]; S[S_DEN] = vals[5]; S[S_ANY] = vals[6]; }
+        if (logic) {
+            if (have_upd) iter_end_dev(S, 1);
+            iter_begin_dev(S, mdiv, predict);
+        }
+    }
+}
 __global__ void k_final_check(double* S) {
     if (S[S_DEAD] == 0.0 && S[S_ANY] == 0.0) { S[S_DEAD] = 1.0; S[S_K] -= 1.0; S[S_EPS] = S[S_EPSP]; }
 }
@@ -576,39 +609,40 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         const char* nf = getenv("PFB_PCG_NO_FUSE_DIR");
         const bool fuse_dir = !(nf && atoi(nf));     // A/B switch: separate update / direction kernels
         while (go) {
-            if (backtrack == 2 || fuse_dir)
+            if (fuse_dir)
+                err = psfconv_apply_partials(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, (void*)st);
+            else if (backtrack == 2)
                 err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);
             else
                 err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
             if (err != PFB_OK) return err;
-            bool begun = false;
-            if (pending_end) {
-                // the previous iteration left [r'.y', |x'-x|^2, |x'|^2] un-reduced: they sit right
-                // behind [p.Ap, r.Ap, Ap.Ap, any(p)] in S, so ONE all-reduce of 7 scalars serves
-                // both reduction points (sharded bands: one RCCL call per iteration instead of two)
-                if ((err = reduce_hook(S_PAP, 7)) != PFB_OK) return err;
-                hipLaunchKernelGGL(k_iter_end_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
-                pending_end = false;
-                begun = true;
-            } else if ((err = reduce_hook(S_PAP, 4)) != PFB_OK) return err;
             if (fuse_dir) {
-                // needs <r,Ap>, <Ap,Ap> even without backtracking (beta comes from rho(alpha))
-                if (!begun)
-                    hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, backtrack == 2 ? 2 : 3);
+                // ONE scalar launch per iteration: the convolution's dots, the previous update's sums
+                // (left pending while nobody can look at k / eps, i.e. while k < minit) and the
+                // bookkeeping; with sharded bands the all-reduce of those 7 (or 4) scalars sits between
+                // the sums and the bookkeeping -- one RCCL call per iteration instead of two.
+                const int predict = backtrack == 2 ? 2 : 3;   // beta always comes from rho(alpha)
+                hipLaunchKernelGGL(k_iter_sums, dim3(1), dim3(256), 0, st, (const double*)plan->partials,
+                                   plan->last_npartials, (const double*)ws, G_used, pending_end ? 1 : 0, S,
+                                   mdiv_d, predict, allreduce ? 0 : 1);
+                if (allreduce) {
+                    if ((err = reduce_hook(S_PAP, pending_end ? 7 : 4)) != PFB_OK) return err;
+                    if (pending_end)
+                        hipLaunchKernelGGL(k_iter_end_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, predict);
+                    else
+                        hipLaunchKernelGGL(k_iter_begin, dim3(1), dim3(1), 0, st, S, mdiv_d, predict);
+                }
+                pending_end = false;
                 G_used = launch_update_dir<T>(n, xcur, rcur, p, Ap, xnew, rnew, S + S_ALPHA, mdiv, ws, st);
-                if (!allreduce) {
+                if (khost + 1 < minit && khost + 1 < maxit) {
+                    pending_end = true;        // summed by the next iteration's k_iter_sums
+                } else if (!allreduce) {
                     hipLaunchKernelGGL(k_final_sum_waves_end, dim3(1), dim3(256), 0, st, ws, G_used, S);
                 } else {
-                hipLaunchKernelGGL(k_final_sum_waves, dim3(1), dim3(256), 0, st, ws, G_used, 4, S,
-                                   (Dst4{{S_RHON, S_NUM, S_DEN, S_ANY}}));
-                // nobody looks at k / eps before the next iteration while k < minit: fold this
-                // reduction point into the next iteration's (only worth it with a real all-reduce)
-                if (khost + 1 < minit && khost + 1 < maxit) {
-                    pending_end = true;
-                } else {
+                    hipLaunchKernelGGL(k_final_sum_waves, dim3(1), dim3(256), 0, st, ws, G_used, 4, S,
+                                       (Dst4{{S_RHON, S_NUM, S_DEN, S_ANY}}));
                     if ((err = reduce_hook(S_RHON, 3)) != PFB_OK) return err;
                     hipLaunchKernelGGL(k_iter_end, dim3(1), dim3(1), 0, st, S, 1);
-                }
                 }
                 { T* t = xcur; xcur = xnew; xnew = t; t = rcur; rcur = rnew; rnew = t; }
             } else {

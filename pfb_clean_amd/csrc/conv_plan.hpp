@@ -51,4 +51,8 @@ inline void prof_mark(pfb_conv_plan* p, hipStream_t st, int k) {
         p->prof_tick++;
     }
 }
+// fftconv.hip: convolution + fused dots left un-summed in plan->partials (see there)
+int psfconv_apply_partials(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                           double wsum, double sigmainv, void* out, const void* dot_with,
+                           const void* dot_with2, void* stream);
 }  // namespace pfb

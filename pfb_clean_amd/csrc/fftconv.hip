@@ -592,7 +592,7 @@ static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, cons
     PFB_REQUIRE(band0 >= 0 && nb > 0 && band0 + nb <= p->nband, PFB_ERR_INVALID,
                 "apply: band range [%d,%d) outside plan (nband=%d)", band0, band0 + nb, p->nband);
     PFB_REQUIRE(x != out, PFB_ERR_INVALID, "apply: out must not alias x");
-    PFB_REQUIRE(!dot_with || dots_out, PFB_ERR_INVALID, "apply: dot_with given without an output");
+    PFB_REQUIRE(!dot_with || dots_out || ndots == 0, PFB_ERR_INVALID, "apply: dot_with given without an output");
     PFB_REQUIRE(!dot_with2 || dot_with, PFB_ERR_INVALID, "apply: dot_with2 needs dot_with");
     hipStream_t st = as_stream(stream);
     double scale = 1.0 / ((double)p->P * (double)p->Q);
@@ -606,7 +606,7 @@ static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, cons
     else
         rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     if (rc != PFB_OK) return rc;
-    if (dot_with) {
+    if (dot_with && ndots > 0) {           // ndots == 0: the caller sums p->partials itself (PCG driver)
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, p->partials,
                            p->last_npartials, ndots, dots_out);
         PFB_HIP_CHECK(hipGetLastError());
@@ -628,3 +628,13 @@ int pfb_psfconv_apply_dots(pfb_conv_plan* p, int band0, int nb, const void* x, c
 }
 
 }  // extern "C"
+
+// internal (cgvec.hip): the convolution with its three fused dots left as per-workgroup partials in
+// plan->partials ([3][plan->last_npartials]) -- the PCG driver sums them in the same launch that does
+// its per-iteration scalar bookkeeping
+int pfb::psfconv_apply_partials(pfb_conv_plan* p, int band0, int nb, const void* x, const void* beam,
+                                double wsum, double sigmainv, void* out, const void* dot_with,
+                                const void* dot_with2, void* stream) {
+    PFB_REQUIRE(dot_with, PFB_ERR_INVALID, "apply_partials: dot_with is required");
+    return apply_common(p, band0, nb, x, beam, wsum, sigmainv, out, dot_with, dot_with2, nullptr, 0, stream);
+}
