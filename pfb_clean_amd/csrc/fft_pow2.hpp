@@ -364,10 +364,18 @@ struct RegFft {
 
     // All threads of the WORKGROUP must call (contains __syncthreads); `lds` is this
     // group's private buffer of NV * LDS_ELEMS elements.
-    template <bool INV, int NV>
+    // X0: parity of the first exchange (DBOFF > 0 only).  A transform with an ODD number of exchanges
+    // ends on the buffer it started on, so back-to-back transforms without a barrier in between must
+    // alternate X0 (0, 1, 0, ...) to keep "the buffer being written was last read two barriers ago".
+    template <bool INV, int NV, int X0 = 0>
     __device__ __forceinline__ static void runN(cplx<T> (&v)[NV][E], cplx<T>* lds, int t,
                                                 const cplx<T>* __restrict__ ptw) {
-        pass<INV, 1, NV>(v, lds, t, ptw);
+        pass<INV, 1, NV, X0>(v, lds, t, ptw);
+    }
+    template <int P = 1> static constexpr int nxch() {       // LDS exchanges per transform
+        constexpr int R = PassRadix<N, E, P>::R;
+        if constexpr (P * R < N) return 1 + nxch<P * R>();
+        else return 0;
     }
     template <bool INV>
     __device__ __forceinline__ static void run(cplx<T> (&v)[E], cplx<T>* lds, int t,

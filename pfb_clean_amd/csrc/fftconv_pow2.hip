@@ -236,19 +236,22 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 //   * a (the T block) of the NEXT item,
 // so that in steady state no load latency is exposed; the column twiddles w_P^n are
 // loaded once per kernel and stay in registers.
-template <typename T, int H, int E>
+// DB: a second set of exchange buffers (when the LDS holds it) -- one barrier per exchange instead of two.
+template <typename T, int H, int E, bool DB = false>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), 2)
 k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
             int nblk, int nitems, size_t T_band, size_t psf_band, int band0, int bstep) {
-    using F = RegFft<T, H, E, false, 0, true>;           // twiddles from LDS: no vmcnt wait in the passes
-    constexpr int TPB = F::TPB;
     constexpr int NVB = FastCfg<T>::NVB;
+    constexpr int XB = NVB * RegFft<T, H, E>::LDS_ELEMS;  // one set of exchange buffers (elements)
+    using F = RegFft<T, H, E, false, DB ? XB : 0, true>;  // twiddles from LDS: no vmcnt wait in the passes
+    constexpr int X1 = (DB && (F::template nxch<1>() & 1)) ? 1 : 0;   // start parity of every other transform
+    constexpr int TPB = F::TPB;
     constexpr int GC = col_groups<H, E>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
-    cplx<T>* lds = ltw + ((F::PTWC + 1) & ~1) + (size_t)g * (NVB * F::LDS_ELEMS);
+    cplx<T>* lds = ltw + ((F::PTWC + 1) & ~1) + (size_t)g * ((DB ? 2 : 1) * XB);
     const int stride = gridDim.x * GC;
     const int niter = (nitems + stride - 1) / stride;           // same for every workgroup
 
@@ -311,7 +314,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
         // ---- even bins
-        F::template runN<false, NVB>(vv, lds, t, ltw);
+        F::template runN<false, NVB, 0>(vv, lds, t, ltw);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
@@ -319,7 +322,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         }
 #pragma unroll
         for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
-        F::template runN<true, NVB>(vv, lds, t, ltw);
+        F::template runN<true, NVB, X1>(vv, lds, t, ltw);
         cplx<T> ev[NVB][E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -327,13 +330,13 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; vv[c][j] = aw[c][j]; }
         }
         // ---- odd bins
-        F::template runN<false, NVB>(vv, lds, t, ltw);
+        F::template runN<false, NVB, 0>(vv, lds, t, ltw);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
             for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
-        F::template runN<true, NVB>(vv, lds, t, ltw);
+        F::template runN<true, NVB, X1>(vv, lds, t, ltw);
         if (active) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -1050,7 +1053,9 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
         if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, ecol<T, NN>()>(&ft->ptwc_col);             \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2<T, NN, ecol<T, NN>()>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>()>), \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false>), \
+            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
+        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true>), \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -1186,11 +1191,21 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
         int grid = ft->num_cu * wg_per_cu;
         const int need = (nitems + GC - 1) / GC;
         if (grid > need) grid = need;
-        hipLaunchKernelGGL((k_col_pow2p<T, H, E>), dim3(grid), dim3(GC * F::TPB),
-                           lds + sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1), st,
-                           (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
-                           (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
-                           p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);
+        // second exchange buffer set when ONE workgroup per CU is resident anyway and it fits: col 0.98 ->
+        // 0.96 ms at 8 x 4096^2 fp32, 1.16 -> 1.10 ms at 4 x 4096^2 fp64; with two workgroups per CU (H = 2048)
+        // the doubled LDS costs residency (fp64 0.245 -> 0.304 ms).  PFB_COL_DB=0 turns it off.
+        static const bool db_on = [] { const char* e = getenv("PFB_COL_DB"); return !e || atoi(e); }();
+        const size_t tab = sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1);
+        if (db_on && wg_per_cu == 1 && 2 * lds + tab <= (size_t)160 * 1024)
+            hipLaunchKernelGGL((k_col_pow2p<T, H, E, true>), dim3(grid), dim3(GC * F::TPB), 2 * lds + tab, st,
+                               (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
+                               (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
+                               p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);
+        else
+            hipLaunchKernelGGL((k_col_pow2p<T, H, E, false>), dim3(grid), dim3(GC * F::TPB), lds + tab, st,
+                               (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
+                               (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
+                               p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);
         return;
     }
     hipLaunchKernelGGL((k_col_pow2<T, H, E>), dim3((nblk + GC - 1) / GC, nb), dim3(GC * F::TPB), lds, st,
