@@ -21,7 +21,10 @@ enum { S_PAP = 0, S_RAP = 1, S_APAP = 2,          // <p,Ap>, <r,Ap>, <Ap,Ap>   (
        S_RHON = 4, S_NUM = 5, S_DEN = 6,          // <r',y'>, |x'-x|^2, |x'|^2 (update kernel)
        S_RHO = 7, S_ALPHA = 8, S_BETA = 9, S_NBT = 10,
        S_DEAD = 11,                               // p became all-zero: later work is a no-op
-       S_K = 12, S_EPS = 13, S_EPSP = 14, S_NBTSUM = 15, S_NSCALAR = 16 };
+       S_K = 12, S_EPS = 13, S_EPSP = 14, S_NBTSUM = 15,
+       S_STOP = 16,                               // the stopping rule fired on the device: later work is a no-op
+       S_TOL = 17, S_MINIT = 18, S_MAXIT = 19,    // the rule's parameters (set once per solve)
+       S_NSCALAR = 20 };
 
 constexpr int RED_BLOCK = 256;
 constexpr int RED_MAX_GRID = 1024;
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(RED_BLOCK)
 k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ p,
                  const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
                  const double* __restrict__ alpha_dev, T mdiv, size_t nvec, double* __restrict__ ws) {
-    const bool dead = alpha_dev[S_DEAD - S_ALPHA] != 0.0;
+    const bool dead = alpha_dev[S_DEAD - S_ALPHA] != 0.0 || alpha_dev[S_STOP - S_ALPHA] != 0.0;
     const T alpha = dead ? T(0) : (T)alpha_dev[0];
     const T beta = (T)alpha_dev[S_BETA - S_ALPHA];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -322,7 +325,7 @@ __global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
 
 // ---- device-side loop bookkeeping of the sync-free driver
 __device__ __forceinline__ void iter_begin_dev(double* S, double mdiv, int predict) {
-    if (S[S_DEAD] != 0.0) return;
+    if (S[S_DEAD] != 0.0 || S[S_STOP] != 0.0) return;
     if (S[S_ANY] == 0.0) {                 // the direction built last iteration is all zero:
         S[S_DEAD] = 1.0;                   // the reference broke BEFORE k += 1 (pcg.py:106-108)
         S[S_K] -= 1.0;
@@ -345,13 +348,18 @@ __device__ __forceinline__ void iter_begin_dev(double* S, double mdiv, int predi
     }
 }
 __device__ __forceinline__ void iter_end_dev(double* S, int fused) {
-    if (S[S_DEAD] != 0.0) return;
+    if (S[S_DEAD] != 0.0 || S[S_STOP] != 0.0) return;
     if (!fused) S[S_BETA] = S[S_RHON] / S[S_RHO];
     S[S_RHO] = S[S_RHON];
-    S[S_K] += 1.0;
+    const double k = S[S_K] + 1.0;
+    const double eps = sqrt(S[S_NUM] / (1e-12 + S[S_DEN]));
+    S[S_K] = k;
     S[S_EPSP] = S[S_EPS];
-    S[S_EPS] = sqrt(S[S_NUM] / (1e-12 + S[S_DEN]));
+    S[S_EPS] = eps;
     S[S_NBTSUM] += S[S_NBT];
+    // the reference's loop condition (pcg.py:86), evaluated where the numbers are: an iteration the host
+    // enqueued speculatively behind this one finds S_STOP set and changes nothing
+    if (!((eps > S[S_TOL] || k < S[S_MINIT]) && k < S[S_MAXIT])) S[S_STOP] = 1.0;
 }
 // the fused update's four sums AND the end-of-iteration bookkeeping in one launch (no all-reduce between)
 __global__ void __launch_bounds__(256)
@@ -408,7 +416,8 @@ k_iter_sums(const double* __restrict__ cp, int ncp, const double* __restrict__ w
 __global__ void k_final_check(double* S) {
     if (S[S_DEAD] == 0.0 && S[S_ANY] == 0.0) { S[S_DEAD] = 1.0; S[S_K] -= 1.0; S[S_EPS] = S[S_EPSP]; }
 }
-__global__ void k_init_state(double* S) {
+__global__ void k_init_state(double* S, double tol, double minit, double maxit) {
+    S[S_TOL] = tol; S[S_MINIT] = minit; S[S_MAXIT] = maxit;
     S[S_RHO] = S[S_RHON];
     S[S_ANY] = S[S_NUM];                   // count(y != 0) = count(p != 0) for p = -y
     S[S_EPS] = 1.0; S[S_EPSP] = 1.0;
@@ -581,7 +590,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(RED_BLOCK), 0, st, ws, G_used, 2, S + S_RHON);
     // S_RHON = <r,y>, S_NUM = count(y != 0): move into place after the hook
     if ((err = reduce_hook(S_RHON, 2)) != PFB_OK) return err;
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, st, S);
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, st, S, tol, (double)minit, (double)maxit);
     if ((err = fetch()) != PFB_OK) return err;
     if (h[S_NUM] == 0.0) {                               // "Initial residual is zero"
         res->status = PFB_PCG_ZERO_RESIDUAL;
@@ -608,6 +617,21 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         bool go = (1.0 > tol || 0 < minit) && 0 < maxit;
         const char* nf = getenv("PFB_PCG_NO_FUSE_DIR");
         const bool fuse_dir = !(nf && atoi(nf));     // A/B switch: separate update / direction kernels
+        // Past minit the stopping rule needs eps after every iteration.  Looking costs a copy + stream sync
+        // (13-24 us, tools/exp_sync_cost.py): a third of an iteration at 1024^2, 1 % at 8 x 4096^2.  Small
+        // problems therefore run ONE iteration ahead: iteration j is enqueued, then the pinned snapshot taken
+        // after iteration j-1 is read; the device evaluates the rule itself (S_STOP) so that the speculative
+        // iteration is a no-op once it fired.  Price: one wasted iteration per solve -- large problems keep
+        // the synchronous look.  PFB_PCG_LOOKAHEAD=0/1 overrides the size rule.
+        bool lookahead = fuse_dir && n <= ((size_t)4 << 20);
+        if (const char* la = getenv("PFB_PCG_LOOKAHEAD")) lookahead = fuse_dir && atoi(la) != 0;
+        if (lookahead && !plan->pcg_pin) {
+            PFB_HIP_CHECK(hipHostMalloc((void**)&plan->pcg_pin, sizeof(double) * 2 * S_NSCALAR, hipHostMallocDefault));
+            PFB_HIP_CHECK(hipEventCreateWithFlags(&plan->pcg_ev[0], hipEventDisableTiming));
+            PFB_HIP_CHECK(hipEventCreateWithFlags(&plan->pcg_ev[1], hipEventDisableTiming));
+        }
+        int slot = 0;
+        bool have_prev = false, stale_h = false;
         while (go) {
             if (fuse_dir)
                 err = psfconv_apply_partials(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, (void*)st);
@@ -659,12 +683,29 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
             }
             ++khost;
             if (khost < minit && khost < maxit) continue;          // cannot stop yet: no need to look
+            if (lookahead && khost < maxit) {
+                double* snap = plan->pcg_pin + (size_t)slot * S_NSCALAR;
+                PFB_HIP_CHECK(hipMemcpyAsync(snap, S, sizeof(double) * S_NSCALAR, hipMemcpyDeviceToHost, st));
+                PFB_HIP_CHECK(hipEventRecord(plan->pcg_ev[slot], st));
+                stale_h = true;
+                if (have_prev) {
+                    PFB_HIP_CHECK(hipEventSynchronize(plan->pcg_ev[slot ^ 1]));
+                    const double* hp = plan->pcg_pin + (size_t)(slot ^ 1) * S_NSCALAR;
+                    if (hp[S_DEAD] != 0.0) { status = PFB_PCG_BREAKDOWN; break; }
+                    if (hp[S_STOP] != 0.0) go = false;             // the iteration just enqueued changes nothing
+                }
+                have_prev = true;
+                slot ^= 1;
+                continue;
+            }
             if ((err = fetch()) != PFB_OK) return err;
+            stale_h = false;
             k = (int)h[S_K];
             eps = h[S_EPS];
             if (h[S_DEAD] != 0.0) { status = PFB_PCG_BREAKDOWN; break; }
             go = (eps > tol || k < minit) && k < maxit;
         }
+        if (status >= 0 && stale_h && (err = fetch()) != PFB_OK) return err;
         if (status < 0) {
             // the direction built by the last iteration has not been looked at yet
             if ((err = reduce_hook(S_ANY, 1)) != PFB_OK) return err;

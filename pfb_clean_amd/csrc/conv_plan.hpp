@@ -37,6 +37,10 @@ struct pfb_conv_plan {
     // optional per-stage timing (bench.py roofline): 4 events per apply, up to PROF_MAX applies
     int prof_on, prof_n, prof_tick;   // prof_on = sampling period (every prof_on-th apply is timed)
     hipEvent_t* prof_ev;
+    // PCG driver (cgvec.hip): pinned snapshots of the solver's state block + their events, for looking at
+    // iteration j-1 while iteration j is already enqueued (created on first use)
+    double* pcg_pin;
+    hipEvent_t pcg_ev[2];
 };
 
 namespace pfb {

@@ -481,6 +481,11 @@ int pfb_psfconv_plan_destroy(pfb_conv_plan* p) {
         for (int k = 0; k < 4 * PROF_MAX; ++k) (void)hipEventDestroy(p->prof_ev[k]);
         free(p->prof_ev);
     }
+    if (p->pcg_pin) {
+        (void)hipHostFree(p->pcg_pin);
+        (void)hipEventDestroy(p->pcg_ev[0]);
+        (void)hipEventDestroy(p->pcg_ev[1]);
+    }
     free(p);
     return PFB_OK;
 }

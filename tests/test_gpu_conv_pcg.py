@@ -545,3 +545,46 @@ def test_closure_preconditioner_is_recognised(amd, golden):
         assert len(calls) == 2                                  # both went the generic way
     finally:
         P.pcg_fused = orig
+
+
+@pmp('bt', [True, False])
+def test_pcg_one_iteration_lookahead_is_invisible(amd, golden, bt, monkeypatch):
+    """Past minit the driver may run one iteration ahead of the host's look at eps (small problems do by
+    default): the speculative iteration must be a no-op once the device-side stopping rule has fired, so
+    every stop regime -- tolerance, tolerance below minit, maxit, breakdown -- gives bit-identical
+    x, r, k, eps with PFB_PCG_LOOKAHEAD=1 and =0, and both agree with the oracle's iteration count."""
+    g = golden('pcg')
+    psfhat, b = g['psfhat'], g['b']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nb, nx, ny = b.shape
+    A = amd.hessian.HessianPsf(psfhat, nx, ny, Q, sigmainv=sigmainv, wsum=1.0)
+    bt_ = torch.from_numpy(b).cuda()
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, np.float64)
+    Ao = lambda v: ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, v, sigmainv=sigmainv, wsum=1.0)
+    cases = [dict(tol=1e-3, maxit=100, minit=1), dict(tol=1e-6, maxit=100, minit=3),
+             dict(tol=1e-2, maxit=100, minit=15), dict(tol=1e-12, maxit=9, minit=2),
+             dict(tol=0.5, maxit=50, minit=0), dict(tol=1e-4, maxit=4, minit=4)]
+    for kw in cases:
+        out = {}
+        for la in ('1', '0'):
+            monkeypatch.setenv('PFB_PCG_LOOKAHEAD', la)
+            x, r, res = amd.pcg.pcg_fused(A, bt_, None, mdiv=sigmainv, backtrack=bt, return_resid=True, **kw)
+            out[la] = (x.cpu().numpy().copy(), r.cpu().numpy().copy(), res.iters, res.eps, res.status, res.matvecs)
+        for a, c in zip(out['1'], out['0']):
+            assert np.array_equal(a, c), kw
+        tr = osv.PCGTrace()
+        xo = osv.pcg(Ao, b, None, M=lambda v: v / sigmainv, backtrack=bt, trace=tr, **kw)
+        assert out['1'][2] == tr.k_exit, (kw, out['1'][2], tr.k_exit)
+        # the fixture's operator is not positive definite (83 backtracks in 100 iterations): without
+        # backtracking the recurrence amplifies rounding differences (1e-5 after 100 iterations)
+        assert relerr(out['1'][0], xo) < (1e-9 if bt else 1e-4)
+    # breakdown two looks late: identity operator converges exactly in one step
+    rng = np.random.default_rng(5)
+    b1 = rng.standard_normal((1, 64, 128))
+    A1 = amd.hessian.HessianPsf(np.zeros((1, 128, 129), dtype=np.complex128), 64, 128, 256, sigmainv=1.0)
+    for la in ('1', '0'):
+        monkeypatch.setenv('PFB_PCG_LOOKAHEAD', la)
+        x, r, res = amd.pcg.pcg_fused(A1, torch.from_numpy(b1).cuda(), None, tol=1e-8, maxit=10, minit=0,
+                                      backtrack=bt, return_resid=True)
+        assert res.status == 3 and res.iters == 0 and res.matvecs == 2
+        assert np.array_equal(x.cpu().numpy(), b1) and not r.cpu().numpy().any()
