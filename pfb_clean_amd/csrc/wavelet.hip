@@ -358,6 +358,94 @@ k_dwt_batched(const T* __restrict__ in_base, size_t in_band, T* __restrict__ alp
 
 
 // ----------------------------------------------------------------- synthesis level
+// ---- staging of a synthesis tile's coefficients: C[ry][cx], ry, cx < 2NC (lo | hi halves in both)
+// When a C row is at least a wavefront wide (fp32 tiles: 2NC >= 64) a WAVE takes a row: the row index is
+// wave-uniform (scalar address / bounds arithmetic), the lane is the column, and only the 2NC - 64 columns
+// beyond the wavefront go through the flat per-element mapping.  The flat mapping cost ~22 VALU
+// instructions per element (division by 2NC, quadrant selects, 64-bit address) -- more than the synthesis
+// arithmetic itself (rocprofv3: 81.8 M VALU wave-instructions per finest-level launch against ~16 M of FMAs).
+template <int NC> struct StageCfg {
+    static constexpr bool ROWS = 2 * NC >= 64;
+    static constexpr int NR = ROWS ? (2 * NC + 3) / 4 : 0;           // rows per wave (4 waves)
+    static constexpr int NREM = ROWS ? 2 * NC - 64 : 0;              // columns beyond the 64 lanes
+    static constexpr int NLR = (NREM * 2 * NC + 255) / 256;
+    static constexpr int NLD = ROWS ? NR + NLR : (4 * NC * NC + 255) / 256;
+};
+template <typename T, int NC>
+__device__ __forceinline__ void coef_load(T (&stage)[StageCfg<NC>::NLD], const T* __restrict__ src, int ldc,
+                                          int nax, int nay, int mx0, int my0, bool skip_ll, int tid) {
+    using S = StageCfg<NC>;
+    if constexpr (S::ROWS) {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const bool hx = lane >= NC;
+        const int gx = mx0 + (hx ? lane - NC : lane);
+        const int coloff = (hx ? nax : 0) + gx;
+        const bool okx = gx < nax;
+#pragma unroll
+        for (int k = 0; k < S::NR; ++k) {
+            const int ry = wv + 4 * k;                               // wave-uniform
+            const bool hy = ry >= NC;
+            const int gy = my0 + (hy ? ry - NC : ry);
+            T v = 0;
+            if (ry < 2 * NC && gy < nay && okx && !(skip_ll && !hy && !hx))
+                v = src[(size_t)((hy ? nay : 0) + gy) * ldc + coloff];
+            stage[k] = v;
+        }
+        if constexpr (S::NREM > 0) {
+#pragma unroll
+            for (int k = 0; k < S::NLR; ++k) {
+                const int e = tid + 256 * k;
+                const int ry = e / S::NREM, cx = 64 + (e - ry * S::NREM);   // cx >= 64 > NC: the hi-x half
+                const bool hy = ry >= NC;
+                const int gy = my0 + (hy ? ry - NC : ry), gx2 = mx0 + cx - NC;
+                T v = 0;
+                if (e < S::NREM * 2 * NC && gy < nay && gx2 < nax)
+                    v = src[(size_t)((hy ? nay : 0) + gy) * ldc + nax + gx2];
+                stage[S::NR + k] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S::NLD; ++k) {
+            const int e = tid + 256 * k;
+            const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+            const bool hy = ry >= NC, hx = cx >= NC;
+            const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
+            T v = 0;
+            if (e < 4 * NC * NC && gy < nay && gx < nax && !(skip_ll && !hy && !hx))
+                v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
+            stage[k] = v;
+        }
+    }
+}
+template <typename T, int NC, int SC>
+__device__ __forceinline__ void coef_store(T* C, const T (&stage)[StageCfg<NC>::NLD], bool skip_ll, int tid) {
+    using S = StageCfg<NC>;
+    if constexpr (S::ROWS) {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < S::NR; ++k) {
+            const int ry = wv + 4 * k;
+            if (ry < 2 * NC && !(skip_ll && ry < NC && lane < NC)) C[ry * SC + lane] = stage[k];
+        }
+        if constexpr (S::NREM > 0) {
+#pragma unroll
+            for (int k = 0; k < S::NLR; ++k) {
+                const int e = tid + 256 * k;
+                const int ry = e / S::NREM, cx = 64 + (e - ry * S::NREM);
+                if (e < S::NREM * 2 * NC) C[ry * SC + cx] = stage[S::NR + k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S::NLD; ++k) {
+            const int e = tid + 256 * k;
+            const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
+            if (e < 4 * NC * NC && !(skip_ll && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
+        }
+    }
+}
+
 // coeffs : this level's (2 nay, 2 nax) block, ld = ldc (y-major)
 // prev   : if non-null, the approx quadrant is prev[c][r] (previous level's image,
 //          row-major ld = ldp) instead of coeffs[r][c]      (wavelets.py:303-309)
@@ -384,20 +472,8 @@ k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int 
     for (int j = 0; j < F; ++j) { lo[j] = f.lo[j]; hi[j] = f.hi[j]; }
     // 1. stage coefficients (all loads first); rows/cols beyond (nay, nax) are only used by
     //    cropped outputs.  coeffs are read row-wise (cx fastest), prev column-wise (ry fastest).
-    constexpr int NE = 4 * NC * NC;
-    constexpr int NLD = (NE + 255) / 256;
-    T stage[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        const bool hy = ry >= NC, hx = cx >= NC;
-        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
-        T v = 0;
-        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
-            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
-        stage[k] = v;
-    }
+    T stage[StageCfg<NC>::NLD];
+    coef_load<T, NC>(stage, src, ldc, nax, nay, mx0, my0, pv != nullptr, (int)threadIdx.x);
     constexpr int NLP = (NC * NC + 255) / 256;
     T stagep[NLP];
     if (pv) {
@@ -411,12 +487,7 @@ k_idwt_level(const T* __restrict__ coeffs, size_t c_band, int ldc, int nax, int 
             stagep[k] = v;
         }
     }
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
-    }
+    coef_store<T, NC, SC>(C, stage, pv != nullptr, (int)threadIdx.x);
     if (pv) {
 #pragma unroll
         for (int k = 0; k < NLP; ++k) {
@@ -481,20 +552,8 @@ __device__ __forceinline__ void idwt_tile_store(T* smem, const T* __restrict__ f
     for (int j = 0; j < F; ++j) { lo[j] = flo[j]; hi[j] = fhi[j]; }
     // 1. stage coefficients (all loads first); rows/cols beyond (nay, nax) are only used by
     //    cropped outputs.  coeffs are read row-wise (cx fastest), prev column-wise (ry fastest).
-    constexpr int NE = 4 * NC * NC;
-    constexpr int NLD = (NE + 255) / 256;
-    T stage[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        const bool hy = ry >= NC, hx = cx >= NC;
-        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
-        T v = 0;
-        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
-            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
-        stage[k] = v;
-    }
+    T stage[StageCfg<NC>::NLD];
+    coef_load<T, NC>(stage, src, ldc, nax, nay, mx0, my0, pv != nullptr, (int)threadIdx.x);
     constexpr int NLP = (NC * NC + 255) / 256;
     T stagep[NLP];
     if (pv) {
@@ -508,12 +567,7 @@ __device__ __forceinline__ void idwt_tile_store(T* smem, const T* __restrict__ f
             stagep[k] = v;
         }
     }
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = threadIdx.x + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
-    }
+    coef_store<T, NC, SC>(C, stage, pv != nullptr, (int)threadIdx.x);
     if (pv) {
 #pragma unroll
         for (int k = 0; k < NLP; ++k) {
@@ -795,20 +849,8 @@ __device__ __forceinline__ void idwt_tile_acc(T* smem, const FinBasis<T>& B, con
     T lo[F], hi[F];
 #pragma unroll
     for (int j = 0; j < F; ++j) { lo[j] = B.lo[j]; hi[j] = B.hi[j]; }
-    constexpr int NE = 4 * NC * NC;
-    constexpr int NLD = (NE + 255) / 256;
-    T stage[NLD];
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = tid + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        const bool hy = ry >= NC, hx = cx >= NC;
-        const int gy = my0 + (hy ? ry - NC : ry), gx = mx0 + (hx ? cx - NC : cx);
-        T v = 0;
-        if (e < NE && gy < nay && gx < nax && !(pv && !hy && !hx))
-            v = src[(size_t)((hy ? nay : 0) + gy) * ldc + (hx ? nax : 0) + gx];
-        stage[k] = v;
-    }
+    T stage[StageCfg<NC>::NLD];
+    coef_load<T, NC>(stage, src, ldc, nax, nay, mx0, my0, pv != nullptr, tid);
     constexpr int NLP = (NC * NC + 255) / 256;
     T stagep[NLP];
     if (pv) {
@@ -823,12 +865,7 @@ __device__ __forceinline__ void idwt_tile_acc(T* smem, const FinBasis<T>& B, con
         }
     }
     __syncthreads();                                   // the previous basis is done with the LDS
-#pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int e = tid + 256 * k;
-        const int ry = e / (2 * NC), cx = e - ry * (2 * NC);
-        if (e < NE && !(pv && ry < NC && cx < NC)) C[ry * SC + cx] = stage[k];
-    }
+    coef_store<T, NC, SC>(C, stage, pv != nullptr, tid);
     if (pv) {
 #pragma unroll
         for (int k = 0; k < NLP; ++k) {
