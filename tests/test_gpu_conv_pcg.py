@@ -588,3 +588,24 @@ def test_pcg_one_iteration_lookahead_is_invisible(amd, golden, bt, monkeypatch):
                                       backtrack=bt, return_resid=True)
         assert res.status == 3 and res.iters == 0 and res.matvecs == 2
         assert np.array_equal(x.cpu().numpy(), b1) and not r.cpu().numpy().any()
+
+
+def test_pcg_degenerate_iteration_limits(amd, golden):
+    """maxit = 0 (the reference's while loop is never entered: x0 comes back, one matvec for the initial
+    residual), maxit < minit (maxit wins), minit = 0 with a tolerance met after the first iteration."""
+    g = golden('pcg')
+    psfhat, b = g['psfhat'], g['b']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nb, nx, ny = b.shape
+    A = amd.hessian.HessianPsf(psfhat, nx, ny, Q, sigmainv=sigmainv, wsum=1.0)
+    bt_ = torch.from_numpy(b).cuda()
+    x0 = torch.from_numpy(g['cube_x0']).cuda()
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, np.float64)
+    Ao = lambda v: ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, v, sigmainv=sigmainv, wsum=1.0)
+    x, _, res = amd.pcg.pcg_fused(A, bt_, x0, mdiv=sigmainv, tol=1e-3, maxit=0, minit=5)
+    assert res.iters == 0 and res.matvecs == 1 and torch.equal(x, x0)
+    for kw in (dict(tol=1e-3, maxit=3, minit=10), dict(tol=10.0, maxit=20, minit=0)):
+        x, _, res = amd.pcg.pcg_fused(A, bt_, x0, mdiv=sigmainv, **kw)
+        tr = osv.PCGTrace()
+        xo = osv.pcg(Ao, b, g['cube_x0'].copy(), M=lambda v: v / sigmainv, trace=tr, **kw)
+        assert res.iters == tr.k_exit and relerr(x.cpu().numpy(), xo) < 1e-10, kw
