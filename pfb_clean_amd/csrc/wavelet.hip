@@ -111,7 +111,8 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
     constexpr int SB = 2 * TA + 1;
     T* A = reinterpret_cast<T*>(smem);        // [NI][SA]   input tile  A[lx][ly]
     T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
-    T* LL = B + NI * SB;                      // [TA][TA+1] LL quadrant for the approx copy
+    T* LL = A;                                // [TA][TA+1] LL quadrant for the approx copy: aliases A, which is dead
+                                              // after the y pass (42 -> 38 KB at F = 8: four workgroups per CU, not three)
     const T* src = in + (size_t)blockIdx.z * in_band;
     T* dst = coeffs + (size_t)blockIdx.z * c_band;
     const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
@@ -239,7 +240,8 @@ __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, con
     constexpr int SB = 2 * TA + 1;
     T* A = smem;                              // [NI][SA]   input tile  A[lx][ly]
     T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
-    T* LL = B + NI * SB;                      // [TA][TA+1] LL quadrant for the approx copy
+    T* LL = A;                                // [TA][TA+1] LL quadrant for the approx copy: aliases A, which is dead
+                                              // after the y pass (42 -> 38 KB at F = 8: four workgroups per CU, not three)
     const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
     T lo[F], hi[F];
 #pragma unroll
@@ -981,7 +983,7 @@ template <typename T>
 static size_t dwt_lds(int F) {
     constexpr int TA = Tile<T>::TA;
     const int NI = 2 * TA + F - 2;
-    return sizeof(T) * ((size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1) + (size_t)TA * (TA + 1));
+    return sizeof(T) * ((size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1));      // LL aliases A
 }
 template <typename T>
 static size_t idwt_lds(int F) {
