@@ -107,10 +107,16 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
             T* __restrict__ approx, size_t a_band, Filt<T> f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
-    constexpr int SA = NI + 1;                // LDS strides (odd -> conflict-free columns)
+    // Both passes decimate by two (index 2q + d): with a plain row the 32 lanes of a half-wave touch only 16
+    // banks (2-way conflicts, 46 % of the LDS-busy cycles in rocprofv3).  A and B are therefore stored
+    // PARITY-SPLIT along the decimated axis -- even samples / rows first, odd ones AO / BO elements later --
+    // so that a tap of fixed parity walks consecutive addresses.
+    constexpr int SA = NI / 2;                // samples of one parity per tile row (NI is even)
+    constexpr int AO = NI * SA;               // offset of the odd-sample half of A
     constexpr int SB = 2 * TA + 1;
+    constexpr int BO = (NI / 2) * SB;         // offset of the odd-row half of B
     T* A = reinterpret_cast<T*>(smem);        // [NI][SA]   input tile  A[lx][ly]
-    T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
+    T* B = A + 2 * AO;                        // [NI][SB]   after the y pass  B[lx][q] (rows parity-split)
     T* LL = A;                                // [TA][TA+1] LL quadrant for the approx copy: aliases A, which is dead
                                               // after the y pass (42 -> 38 KB at F = 8: four workgroups per CU, not three)
     const T* src = in + (size_t)blockIdx.z * in_band;
@@ -151,7 +157,7 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
             if (e < NI * NWV) {
 #pragma unroll
                 for (int c = 0; c < VW; ++c)
-                    if (ly0 + c >= 0 && ly0 + c < NI) A[lx * SA + ly0 + c] = stage[k].e[c];
+                    if (ly0 + c >= 0 && ly0 + c < NI) A[((ly0 + c) & 1) * AO + lx * SA + ((ly0 + c) >> 1)] = stage[k].e[c];
             }
         }
     } else {
@@ -170,28 +176,37 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
         for (int k = 0; k < NLD; ++k) {
             const int e = threadIdx.x + 256 * k;
             const int lx = e / NI, ly = e - lx * NI;
-            if (e < NI * NI) A[lx * SA + ly] = stage[k];
+            if (e < NI * NI) A[(ly & 1) * AO + lx * SA + (ly >> 1)] = stage[k];
         }
     }
     __syncthreads();
     // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
     for (int e = threadIdx.x; e < NI * TA; e += 256) {
         const int lx = e / TA, qq = e - lx * TA;
-        const T* a = A + lx * SA + 2 * qq + F - 1;
+        const T* a = A + lx * SA + qq;
         T sl = 0, sh = 0;
 #pragma unroll
-        for (int j = 0; j < F; ++j) { const T v = a[-j]; sl += lo[j] * v; sh += hi[j] * v; }
-        B[lx * SB + qq] = sl;
-        B[lx * SB + TA + qq] = sh;
+        for (int j = 0; j < F; ++j) {                          // sample 2 qq + d, d = F-1-j
+            const int d = F - 1 - j;
+            const T v = a[(d & 1) * AO + (d >> 1)];
+            sl += lo[j] * v; sh += hi[j] * v;
+        }
+        T* brow = B + (lx & 1) * BO + (lx >> 1) * SB;
+        brow[qq] = sl;
+        brow[TA + qq] = sh;
     }
     __syncthreads();
     // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c (x coefficient) lo & hi
     for (int e = threadIdx.x; e < 2 * TA * TA; e += 256) {
         const int r = e / TA, cc = e - r * TA;
-        const T* b = B + (2 * cc + F - 1) * SB + r;
+        const T* b = B + cc * SB + r;
         T sl = 0, sh = 0;
 #pragma unroll
-        for (int j = 0; j < F; ++j) { const T v = b[-j * SB]; sl += lo[j] * v; sh += hi[j] * v; }
+        for (int j = 0; j < F; ++j) {                          // row 2 cc + d, d = F-1-j
+            const int d = F - 1 - j;
+            const T v = b[(d & 1) * BO + (d >> 1) * SB];
+            sl += lo[j] * v; sh += hi[j] * v;
+        }
         const bool hiy = r >= TA;
         const int rr = hiy ? r - TA : r;
         const int gy = oy0 + rr, gx = ox0 + cc;
@@ -236,10 +251,16 @@ __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, con
                                          int ox0, int oy0) {
 
     constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
-    constexpr int SA = NI + 1;                // LDS strides (odd -> conflict-free columns)
+    // Both passes decimate by two (index 2q + d): with a plain row the 32 lanes of a half-wave touch only 16
+    // banks (2-way conflicts, 46 % of the LDS-busy cycles in rocprofv3).  A and B are therefore stored
+    // PARITY-SPLIT along the decimated axis -- even samples / rows first, odd ones AO / BO elements later --
+    // so that a tap of fixed parity walks consecutive addresses.
+    constexpr int SA = NI / 2;                // samples of one parity per tile row (NI is even)
+    constexpr int AO = NI * SA;               // offset of the odd-sample half of A
     constexpr int SB = 2 * TA + 1;
+    constexpr int BO = (NI / 2) * SB;         // offset of the odd-row half of B
     T* A = smem;                              // [NI][SA]   input tile  A[lx][ly]
-    T* B = A + NI * SA;                       // [NI][SB]   after the y pass  B[lx][q]
+    T* B = A + 2 * AO;                        // [NI][SB]   after the y pass  B[lx][q] (rows parity-split)
     T* LL = A;                                // [TA][TA+1] LL quadrant for the approx copy: aliases A, which is dead
                                               // after the y pass (42 -> 38 KB at F = 8: four workgroups per CU, not three)
     const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
@@ -277,7 +298,7 @@ __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, con
             if (e < NI * NWV) {
 #pragma unroll
                 for (int c = 0; c < VW; ++c)
-                    if (ly0 + c >= 0 && ly0 + c < NI) A[lx * SA + ly0 + c] = stage[k].e[c];
+                    if (ly0 + c >= 0 && ly0 + c < NI) A[((ly0 + c) & 1) * AO + lx * SA + ((ly0 + c) >> 1)] = stage[k].e[c];
             }
         }
     } else {
@@ -296,28 +317,37 @@ __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, con
         for (int k = 0; k < NLD; ++k) {
             const int e = threadIdx.x + 256 * k;
             const int lx = e / NI, ly = e - lx * NI;
-            if (e < NI * NI) A[lx * SA + ly] = stage[k];
+            if (e < NI * NI) A[(ly & 1) * AO + lx * SA + (ly >> 1)] = stage[k];
         }
     }
     __syncthreads();
     // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
     for (int e = threadIdx.x; e < NI * TA; e += 256) {
         const int lx = e / TA, qq = e - lx * TA;
-        const T* a = A + lx * SA + 2 * qq + F - 1;
+        const T* a = A + lx * SA + qq;
         T sl = 0, sh = 0;
 #pragma unroll
-        for (int j = 0; j < F; ++j) { const T v = a[-j]; sl += lo[j] * v; sh += hi[j] * v; }
-        B[lx * SB + qq] = sl;
-        B[lx * SB + TA + qq] = sh;
+        for (int j = 0; j < F; ++j) {                          // sample 2 qq + d, d = F-1-j
+            const int d = F - 1 - j;
+            const T v = a[(d & 1) * AO + (d >> 1)];
+            sl += lo[j] * v; sh += hi[j] * v;
+        }
+        T* brow = B + (lx & 1) * BO + (lx >> 1) * SB;
+        brow[qq] = sl;
+        brow[TA + qq] = sh;
     }
     __syncthreads();
     // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c (x coefficient) lo & hi
     for (int e = threadIdx.x; e < 2 * TA * TA; e += 256) {
         const int r = e / TA, cc = e - r * TA;
-        const T* b = B + (2 * cc + F - 1) * SB + r;
+        const T* b = B + cc * SB + r;
         T sl = 0, sh = 0;
 #pragma unroll
-        for (int j = 0; j < F; ++j) { const T v = b[-j * SB]; sl += lo[j] * v; sh += hi[j] * v; }
+        for (int j = 0; j < F; ++j) {                          // row 2 cc + d, d = F-1-j
+            const int d = F - 1 - j;
+            const T v = b[(d & 1) * BO + (d >> 1) * SB];
+            sl += lo[j] * v; sh += hi[j] * v;
+        }
         const bool hiy = r >= TA;
         const int rr = hiy ? r - TA : r;
         const int gy = oy0 + rr, gx = ox0 + cc;
