@@ -30,7 +30,7 @@ template <int NR, int NW> void run(const char* name, size_t n, v4** bufs, v4** d
     hipMemcpy(dptr, h.data(), sizeof(v4*) * (NR + NW), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double best = 0; int bg = 0, bb = 0;
-    for (int block : {256, 512, 1024})
+    for (int block : {64, 128, 256, 512, 1024})
         for (int per_cu : {1, 2, 4, 8, 16, 32}) {
             const int grid = 256 * per_cu;
             hipLaunchKernelGGL((k<NR, NW>), dim3(grid), dim3(block), 0, 0, (const v4* const*)dptr, dptr + NR, n, 0.5f);
