@@ -344,3 +344,30 @@ def test_prox21m_numba_matches_prox21m(amd, nband, nbasis, nymax, nxmax, lam, si
     res = amd.p21m.prox_21m(v / sigma, lam / sigma, weight=w)
     amd.p21m.prox_21m_numba(v, vout, lam, sigma=sigma, weight=w)
     np.testing.assert_array_almost_equal(res, vout, decimal=8)
+
+
+@pytest.mark.parametrize('case', [(2, 256, 192, ['self', 'db6', 'db7', 'db8', 'db9'], 2),
+                                  (1, 300, 260, ['db9', 'db2', 'db7'], 3),
+                                  (1, 514, 390, ['self', 'db1', 'db6', 'db9'], 2)],
+                         ids=['db6-9', 'db9-mixed-3lev', 'wide-mixed'])
+@pytest.mark.parametrize('rdt', [np.float64, np.float32])
+def test_long_filters_against_oracle(amd, case, rdt):
+    """Filters beyond the reference tests' db5 (F = 12 .. 18): the FMAX = 18 instantiations of the batched
+    level kernels and the wide-tile staging paths (tile rows wider than a wavefront by up to 16 columns)."""
+    nb, nx, ny, bases, nl = case
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((nb, nx, ny)).astype(rdt)
+    po = owv.Psi(nb, nx, ny, bases, nl)
+    a_ref = np.zeros((nb, po.nbasis, po.Nymax, po.Nxmax))
+    po.dot(x.astype(np.float64), a_ref)
+    psi = amd.Psi(nb, nx, ny, bases, nl, 1)
+    a = np.zeros(a_ref.shape, dtype=rdt)
+    psi.dot(x, a)
+    c = rng.standard_normal(a_ref.shape).astype(rdt)
+    xo_ref = np.zeros((nb, nx, ny))
+    po.hdot(c.astype(np.float64), xo_ref)
+    xo = np.full((nb, nx, ny), np.nan, dtype=rdt)
+    psi.hdot(c, xo)
+    tol = 1e-12 if rdt == np.float64 else 2e-5
+    assert np.abs(a - a_ref).max() < tol * np.abs(a_ref).max()
+    assert np.abs(xo - xo_ref).max() < tol * np.abs(xo_ref).max()
