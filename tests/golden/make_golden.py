@@ -26,7 +26,7 @@ _refstubs.install(ROOT)
 
 from pfb.operators.psf import psf_convolve_slice, psf_convolve_cube  # noqa: E402
 from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube, hessian_psf_slice  # noqa: E402
-from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist, cg_dct  # noqa: E402
+from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist, cg_dct, cg  # noqa: E402
 from pfb.opt.power_method import power_method  # noqa: E402
 from pfb.opt.primal_dual import primal_dual_optimised  # noqa: E402
 from pfb.operators.psi import Psi  # noqa: E402
@@ -513,7 +513,30 @@ def gen_misc():
     print('misc.npz', len(out), 'arrays')
 
 
+def gen_cg():
+    """Plain CG (pcg.py:12-50: no preconditioner, eps = <r, r> un-normalised) on the PSD PSF Hessian + Tikhonov
+    of one 2-band cube: fixed iteration counts, a tolerance stop and a warm start."""
+    out = {}
+    rng = np.random.default_rng(480)
+    nb, nx, ny, P, Q = 2, 40, 48, 80, 96
+    psfhat = psd_psfhat(rng, nb, P, Q)
+    sigmainv = 0.05
+    b = rng.standard_normal((nb, nx, ny))
+    x0 = 0.1 * rng.standard_normal((nb, nx, ny))
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+
+    def A(v):
+        return psf_convolve_cube(xpad, xhat, xout, psfhat, Q, v, nthreads=1).copy() + sigmainv * v
+    out.update(psfhat=psfhat, b=b, x0=x0, sigmainv=np.float64(sigmainv), Q=np.int64(Q))
+    for k in (1, 4, 12):
+        out[f'k{k}'] = cg(A, b, None, tol=0.0, maxit=k, verbosity=0)
+    out['tol'] = cg(A, b, None, tol=1e-6, maxit=500, verbosity=0)
+    out['warm_k5'] = cg(A, b, x0, tol=0.0, maxit=5, verbosity=0)
+    np.savez_compressed(os.path.join(HERE, 'cg.npz'), **out)
+    print('cg.npz', len(out))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark', 'misc']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark', 'misc', 'cg']
     for w in which:
         globals()['gen_' + w]()

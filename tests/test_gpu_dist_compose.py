@@ -652,3 +652,27 @@ def test_freqmul_parametrisation_against_reference_vectors():
         xt, vt = torch.from_numpy(x0).cuda(), torch.from_numpy(v).cuda()
         got = dfunc(xt, vt)
         assert got.is_cuda and np.abs(got.cpu().numpy() - g[f'par_{mode}_dfunc']).max() < 1e-12
+
+
+@pytest.mark.parametrize('kind', ['numpy', 'tensor'])
+def test_plain_cg_against_reference_vectors(kind):
+    """pcg.py:12-50 (cg) on the GPU against the reference's outputs (tests/golden/cg.npz)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pfb_clean_amd.opt.pcg import cg
+    from pfb_clean_amd.operators.hessian import HessianPsf
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cg.npz'))
+    b, Q, sigmainv = g['b'], int(g['Q']), float(g['sigmainv'])
+    nb, nx, ny = b.shape
+    A = HessianPsf(g['psfhat'], nx, ny, Q, sigmainv=sigmainv)
+    wrap = (lambda a: torch.from_numpy(np.array(a)).cuda()) if kind == 'tensor' else (lambda a: np.array(a))
+    back = (lambda t: t.cpu().numpy()) if kind == 'tensor' else (lambda a: a)
+    for k in (1, 4, 12):
+        x = back(cg(A, wrap(b), None, tol=0.0, maxit=k, verbosity=0))
+        assert np.abs(x - g[f'k{k}']).max() < 1e-9 * np.abs(g[f'k{k}']).max(), k
+    x = back(cg(A, wrap(b), None, tol=1e-6, maxit=500, verbosity=0))
+    assert np.abs(x - g['tol']).max() < 1e-6 * np.abs(g['tol']).max()
+    x0 = wrap(g['x0'])
+    x = back(cg(A, wrap(b), x0, tol=0.0, maxit=5, verbosity=0))
+    assert np.abs(x - g['warm_k5']).max() < 1e-9 * np.abs(g['warm_k5']).max()
+    assert np.array_equal(back(x0), g['x0'])                        # x0 is copied, not updated (pcg.py:23)

@@ -513,3 +513,17 @@ def test_freqmul_parametrisation_pinned(golden):
         assert_allclose(finv(func(x0)), g[f'par_{mode}_finv'], rtol=1e-7, atol=1e-9)
         assert_allclose(dfunc(x0, v), g[f'par_{mode}_dfunc'], rtol=1e-12, atol=1e-13)
         assert_allclose(dhfunc(x0, v), g[f'par_{mode}_dhfunc'], rtol=1e-12, atol=1e-13)
+
+
+def test_plain_cg_pinned(golden):
+    """pcg.py:12-50 (cg): fixed iteration counts, tolerance stop, warm start -- the reference's outputs."""
+    g = golden('cg')
+    psfhat, b, Q, sigmainv = g['psfhat'], g['b'], int(g['Q']), float(g['sigmainv'])
+    xpad, xhat, xout = fc.make_scratch(psfhat, Q, b.shape, np.float64)
+
+    def A(v):
+        return fc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, v).copy() + sigmainv * v
+    for k in (1, 4, 12):
+        assert_allclose(sv.cg(A, b, None, tol=0.0, maxit=k, verbosity=0), g[f'k{k}'], rtol=1e-10, atol=1e-12)
+    assert_allclose(sv.cg(A, b, None, tol=1e-6, maxit=500, verbosity=0), g['tol'], rtol=1e-7, atol=1e-9)
+    assert_allclose(sv.cg(A, b, g['x0'], tol=0.0, maxit=5, verbosity=0), g['warm_k5'], rtol=1e-10, atol=1e-12)
