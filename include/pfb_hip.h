@@ -179,7 +179,9 @@ typedef int (*pfb_allreduce_fn)(void* ctx, double* dev_buf, int count, void* str
 typedef struct {
     int    status;       /* PFB_PCG_* */
     int    iters;        /* k at exit */
-    int    matvecs;      /* number of A applications (k + 1 unless early exit) */
+    int    matvecs;      /* number of A applications the REFERENCE loop makes (k + 1 unless early exit); small
+                          * problems run one iteration ahead of the host's look at eps past minit, so one
+                          * further, discarded application may have been executed (PFB_PCG_LOOKAHEAD=0: never) */
     int    backtracks;   /* total backtracking steps taken */
     double eps;          /* last norm_diff(x, xp) */
     double rnorm;        /* last r.y */
