@@ -676,3 +676,28 @@ def test_plain_cg_against_reference_vectors(kind):
     x = back(cg(A, wrap(b), x0, tol=0.0, maxit=5, verbosity=0))
     assert np.abs(x - g['warm_k5']).max() < 1e-9 * np.abs(g['warm_k5']).max()
     assert np.array_equal(back(x0), g['x0'])                        # x0 is copied, not updated (pcg.py:23)
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, band shard,
+    all-reduce hook, max-over-ranks timing, one JSON line from rank 0) -- rehearsed with two ranks sharing
+    the test GPU over gloo (RCCL refuses two ranks on one device; PFB_DIST_BACKEND is a bench-only switch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFB_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--size', '1024', '--bands', '4', '--steps', '6',
+           '--warmup', '2', '--no-cpu']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 6 and d['matvecs'] == 7
+    assert d['config']['bands_per_gpu'] == 2 and d['value'] > 0 and d['scaling'] == 'strong'
+    assert d['roofline'] is not None and d['cpu_baseline'] is None
