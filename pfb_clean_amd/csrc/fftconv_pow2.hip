@@ -34,6 +34,18 @@
 #include <vector>
 #include <cstdlib>
 
+// This file is compiled into TWO objects (csrc/Makefile): PFB_POW2_PART=1 -- everything but the column
+// kernels -- and PFB_POW2_PART=2 -- the column kernels and their launcher, built with LLVM's max-ILP machine
+// scheduler (-mllvm -amdgpu-sched-strategy=max-ilp).  Their occupancy is pinned by the launch bounds, so
+// the default occupancy-driven scheduling only costs them instruction-level parallelism: col 0.977 ->
+// 0.904 ms fp32 and 1.152 -> 1.078 ms fp64 at 4096^2; the row kernels LOSE 5-25 % under the same switch,
+// hence the split.  (0 = one object with everything, default scheduler.)
+#ifndef PFB_POW2_PART
+#define PFB_POW2_PART 0
+#endif
+#define PFB_POW2_COL  (PFB_POW2_PART != 1)
+#define PFB_POW2_REST (PFB_POW2_PART != 2)
+
 namespace pfb {
 
 // elements per thread: the column kernel favours occupancy (small register arrays, it
@@ -126,6 +138,7 @@ __host__ __device__ inline void block_of_bin(int v, int L, int nvb, int* blk, in
 }
 inline int fast_nblocks(int L, int nvb) { return (L + nvb) / nvb + L / nvb; }
 
+#if PFB_POW2_REST
 // psf_l[band][blk][pu][mu][c] = psfhat[band][2 mu + pu][v]
 template <typename T>
 __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>* __restrict__ psf_l,
@@ -151,6 +164,9 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
     }
 }
 
+#endif  // PFB_POW2_REST
+
+#if PFB_POW2_COL
 // ------------------------------------------------------------------------ column
 template <typename T, int H, int E>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), (E >= 16 ? 2 : FastCfg<T>::WCOL))
@@ -349,6 +365,9 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     }
 }
 
+#endif  // PFB_POW2_COL
+
+#if PFB_POW2_REST
 // ------------------------------------------------------------------- row forward
 // Hermitian post-processing of one parity: the group's transform Z (registers, natural order)
 // goes to LDS, then every lane produces the NVB bins of one block for one row and the G lanes
@@ -976,6 +995,11 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     }
 }
 
+#endif  // PFB_POW2_REST
+
+// size switch helper
+#define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
+
 // -------------------------------------------------------------------- host side
 struct FastTables {            // device tables owned by the plan (stored behind p->fast_tables)
     void* ptw_col;
@@ -989,7 +1013,11 @@ struct FastTables {            // device tables owned by the plan (stored behind
     int inv_persistent;        // PFB_INV_PERSIST (default 1): persistent pipelined inverse row kernel where it fits
     int num_cu;
 };
+// the column object's entry points (defined under PFB_POW2_COL below)
+int pow2_col_set_attr(int dtype, int H);
+int pow2_col_launch(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st);
 
+#if PFB_POW2_REST
 template <typename T, int N, int E>
 static int upload_ptw(void** dev) {
     constexpr int n = ptw_total<N, E>();
@@ -1040,8 +1068,6 @@ static int prep_fwdp(void** table) {
     return PFB_OK;
 }
 
-// size switch helpers -------------------------------------------------------------
-#define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 
 template <typename T>
 static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
@@ -1051,12 +1077,7 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     switch (H) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, ecol<T, NN>()>(&ft->ptw_col);                          \
         if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, ecol<T, NN>()>(&ft->ptwc_col);             \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2<T, NN, ecol<T, NN>()>), \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false>), \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
-        if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true>), \
-            hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
+        if (rc == PFB_OK) rc = pow2_col_set_attr(p->dtype, NN); break;
         PFB_POW2_SIZES(X)
 #undef X
         default: break;
@@ -1168,6 +1189,9 @@ int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st) {
     return p->dtype == PFB_F32 ? set_psfhat_t<float>(p, psfhat, st) : set_psfhat_t<double>(p, psfhat, st);
 }
 
+#endif  // PFB_POW2_REST
+
+#if PFB_POW2_COL
 template <typename T, int H>
 static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st) {
     constexpr int E = ecol<T, H>();
@@ -1212,6 +1236,43 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
                        (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
                        (const cplx<T>*)ft->ptw_col, nblk, p->T_elems_per_band, p->psf_elems_per_band, band0);
 }
+
+template <typename T>
+static int col_set_attr_t(int H) {
+    constexpr int lds_max = 160 * 1024;
+    switch (H) {
+#define X(NN) case NN:                                                                                        \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2<T, NN, ecol<T, NN>()>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
+        PFB_POW2_SIZES(X)
+#undef X
+        default: set_error("pow2: unsupported nx"); return PFB_ERR_UNSUPPORTED;
+    }
+    return PFB_OK;
+}
+int pow2_col_set_attr(int dtype, int H) {
+    return dtype == PFB_F32 ? col_set_attr_t<float>(H) : col_set_attr_t<double>(H);
+}
+template <typename T>
+static int col_launch_t(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st) {
+    switch (p->nx) {
+#define X(NN) case NN: launch_col<T, NN>(p, ft, band0, nb, st); break;
+        PFB_POW2_SIZES(X)
+#undef X
+        default: set_error("pow2_apply: unsupported nx"); return PFB_ERR_UNSUPPORTED;
+    }
+    return PFB_OK;
+}
+int pow2_col_launch(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st) {
+    return p->dtype == PFB_F32 ? col_launch_t<float>(p, ft, band0, nb, st) : col_launch_t<double>(p, ft, band0, nb, st);
+}
+#endif  // PFB_POW2_COL
+
+#if PFB_POW2_REST
 
 template <typename T, int L>
 static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, const void* x,
@@ -1297,12 +1358,7 @@ static int apply_t(pfb_conv_plan* p, int band0, int nb, const void* x, const voi
         default: set_error("pow2_apply: unsupported ny"); return PFB_ERR_UNSUPPORTED;
     }
     prof_mark(p, st, 1);
-    switch (H) {
-#define X(NN) case NN: launch_col<T, NN>(p, ft, band0, nb, st); break;
-        PFB_POW2_SIZES(X)
-#undef X
-        default: set_error("pow2_apply: unsupported nx"); return PFB_ERR_UNSUPPORTED;
-    }
+    if (int rc = pow2_col_launch(p, ft, band0, nb, st); rc != PFB_OK) return rc;
     prof_mark(p, st, 2);
     switch (L) {
 #define X(NN) case NN: launch_row_inv<T, NN>(p, ft, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st); break;
@@ -1320,5 +1376,6 @@ int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* b
     return p->dtype == PFB_F32 ? apply_t<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st)
                                : apply_t<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
 }
+#endif  // PFB_POW2_REST
 
 }  // namespace pfb
