@@ -1,37 +1,48 @@
 #!/usr/bin/env python
 """
-bench.py -- PCG matvecs/sec on the BASELINE workload: 4096 x 4096 x 8-band cube PCG
-(fluxmop semantics: ONE system over all bands, global dot products), fp32, synthetic
-dirty/PSF cubes, bands sharded over N GPUs with one small RCCL all-reduce per
-reduction point.
+bench.py -- the BASELINE workloads on MI355X, one JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--workload pcg|pd]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one PCG iteration (one A^H A apply on the whole cube + the fused vector
-updates and reductions).  The timed region is ONE pfb_pcg_solve of exactly K iterations
-(tol = 0, minit = maxit = K => K + 1 matvecs), all inputs resident in HBM, bracketed by
-barrier + synchronize; time = max over ranks; value = (K + 1) cube-matvecs / time.
-Total work is fixed as N grows => "scaling": "strong".
+--workload pcg (default, the headline metric): PCG matvecs/sec on the 4096 x 4096 x 8-band cube
+(fluxmop semantics: ONE system over all bands, global dot products), fp32, synthetic dirty/PSF
+cubes, bands sharded over N GPUs with one small RCCL all-reduce per reduction point.
+A "step" is one PCG iteration (one A^H A apply on the whole cube + the fused vector updates and
+reductions).  A timed region is ONE pfb_pcg_solve of exactly K iterations (tol = 0, minit =
+maxit = K => K + 1 matvecs), everything resident in HBM, bracketed by barrier + synchronize,
+time = max over ranks.  The region is repeated R times; `value` = (K + 1) cube-matvecs / MEDIAN
+time, min / max alongside.  Total work is fixed as N grows => "scaling": "strong".
+
+--workload pd: BASELINE config #4, the backward step of the forward-backward loop: K iterations
+of primal_dual_optimised on a 2048 x 2048 x 4-band cube (psi / psi^H with self + db1..db4, 3
+levels, dual update, one PSF convolution for the gradient), value = iterations / s.
+
+`python bench.py --gpus N` WITHOUT a launcher (WORLD_SIZE unset) starts the N ranks itself as a
+child `torch.distributed.run` before anything touches the GPU and relays rank 0's line;
+--gpus that disagrees with WORLD_SIZE is an error.
 
 Extra objects on the JSON line:
-  roofline     the FFT-convolution kernel group (row-fwd, column, row-inv = one band
-               matvec), algorithmic bytes B_alg = s (2 nx ny + 2 nx_psf (ny_psf/2+1)) per
-               band-matvec (SURVEY 8d / BASELINE.md 4) over its HIP-event-measured
-               duration inside the timed solve; per-stage times alongside.
-  cpu_baseline the numpy/scipy.fft oracle ("port" of the reference's CPU path; ducc0 is
-               not installable) timed on this host on ONE band of the same cube for a
-               bounded number of iterations, converted to cube-matvecs/s.
+  roofline     pcg: the FFT-convolution kernel group (row-fwd, column, row-inv = one band matvec),
+               algorithmic bytes B_alg = s (2 nx ny + 2 nx_psf (ny_psf/2+1)) per band-matvec
+                over its HIP-event-measured duration inside the timed solves (events
+               recorded by the library on the solver's stream); per-stage times alongside.
+               pd: the whole iteration's algorithmic bytes over its duration.
+  cpu_baseline the numpy/scipy.fft oracle ("port" of the reference's CPU path; ducc0 is not
+               installable) on this host: ALL bands of the same cube solved concurrently, one
+               process per band (the reference runs bands concurrently too, pcg.py:320-356), a
+               bounded number of iterations; the cube rate is measured, not extrapolated.
+  parity       max relative difference GPU vs CPU oracle of one band-matvec on the same input.
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -39,10 +50,60 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured copy)
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each (median reported)')
+    ap.add_argument('--workload', default='pcg', choices=['pcg', 'pd'])
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--bands', type=int, default=None)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline / parity leg')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--cpu-cores', type=int, default=0,
+                    help='host cores for the cpu_baseline leg (0 = the CPU share of this process, at most 16 per GPU)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='run the band-sharded code path (all-reduce hook) even at world size 1')
+    ap.add_argument('--cpu-worker', nargs=5, metavar=('DIR', 'BAND', 'THREADS', 'ITERS', 'SIGMAINV'),
+                    help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD process (nothing in this process has
+    touched the GPU yet -- never exec / re-launch after that) and exit with its code."""
+    if 'WORLD_SIZE' in os.environ:
+        world = int(os.environ['WORLD_SIZE'])
+        if args.gpus != world:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ------------------------------------------------------------------------- synthetic inputs
 def synth_band(band, nband, nx, ny, dtype, device):
     """psfhat of one band: non-negative Poisson uv weights under a Gaussian
     taper, normalised so that sum_band psf peaks at 1 (spotless.py:148-149).  Generated
     on the device (setup, not timed) with a per-band seed 420 + band."""
+    import torch
     P, Q = 2 * nx, 2 * ny
     g = torch.Generator(device=device)
     g.manual_seed(420 + band)
@@ -61,6 +122,8 @@ def synth_band(band, nband, nx, ny, dtype, device):
 def synth_model(band, nx, ny, dtype, device):
     """25 elliptical Gaussians + 10 unit point sources, spectral index -0.7 +- 0.1
     (mirrors tests/test_spotless.py:88-107, tests/test_klean.py:71-78)."""
+    import numpy as np
+    import torch
     rng = np.random.default_rng(420)
     yy = torch.arange(ny, device=device, dtype=torch.float32)[None, :]
     xx = torch.arange(nx, device=device, dtype=torch.float32)[:, None]
@@ -80,45 +143,79 @@ def synth_model(band, nx, ny, dtype, device):
     return model.to(dtype)
 
 
+def _median(v):
+    s = sorted(v)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
+# ---------------------------------------------------------------------------------- main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--size', type=int, default=4096)
-    ap.add_argument('--bands', type=int, default=8)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
-    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--cpu-seconds', type=float, default=20.0)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.cpu_worker:
+        return cpu_worker(*args.cpu_worker)
+    maybe_launch(args)
+
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    use_pg = world > 1 or args.force_dist
+    if use_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
         # RCCL in production; PFB_DIST_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 path
         dist.init_process_group(os.environ.get('PFB_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % max(ndev, 1))
     device = torch.device('cuda', local_rank % max(ndev, 1))
+    ctx = dict(args=args, world=world, rank=rank, device=device, use_pg=use_pg)
+    out = bench_pd(ctx) if args.workload == 'pd' else bench_pcg(ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if use_pg:
+        dist.destroy_process_group()
 
+
+def _timed_regions(run, barrier, repeats, world, device):
+    """`repeats` timed regions of run() between barrier + synchronize; per-region time = max over ranks."""
+    import torch
+    import torch.distributed as dist
+    times, last = [], None
+    for _ in range(max(1, repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        last = run()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        times.append(dt)
+    return times, last
+
+
+def bench_pcg(ctx):
+    import torch
+    import torch.distributed as dist
+    args, world, rank, device = ctx['args'], ctx['world'], ctx['rank'], ctx['device']
     from pfb_clean_amd.operators.psf import PsfConvPlan
     from pfb_clean_amd.operators.hessian import HessianPsf
     from pfb_clean_amd.opt.pcg import pcg_fused
     from pfb_clean_amd.dist import shard_bands, global_max
 
-    n = args.size
-    nband = args.bands
+    n = args.size or 4096
+    nband = args.bands or 8
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     band0, nb = shard_bands(nband, rank, world)
     if nb == 0:
         raise SystemExit("more ranks than bands")
     Q = 2 * n
 
-    # ---------------------------------------------------------------- synthetic inputs
     psfhat = torch.stack([synth_band(band0 + k, nband, n, n, dtype, device) for k in range(nb)])
     plan = PsfConvPlan(psfhat, n, n, Q)
     model = torch.stack([synth_model(band0 + k, n, n, dtype, device) for k in range(nb)])
@@ -131,37 +228,27 @@ def main():
     del model
     torch.cuda.synchronize()
 
-    def solve(iters, **kw):
+    def solve(iters):
         return pcg_fused(A, b, None, mdiv=sigmainv, tol=0.0, maxit=iters, minit=iters,
-                         backtrack=True, distributed=world > 1, **kw)
+                         backtrack=True, distributed=ctx['use_pg'])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ------------------------------------------------------------------ warmup + timing
     if args.warmup > 0:
         solve(args.warmup)
     barrier()
     plan.set_profiling(4)        # every 4th launch group carries the stage events (~6 us each on the stream)
-    t0 = time.perf_counter()
-    x, _, res = solve(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
+    times, (x, _, res) = _timed_regions(lambda: solve(args.steps), barrier, args.repeats, world, device)
     stage_ms, napply = plan.get_profile()
     plan.set_profiling(False)
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
     assert res.iters == args.steps and res.matvecs == args.steps + 1, (res.iters, res.matvecs)
     matvecs = res.matvecs
+    elapsed = _median(times)
     value = matvecs / elapsed
 
-    # ---------------------------------------------------------------------- roofline
     s = 4 if dtype == torch.float32 else 8
     balg_band = s * (2 * n * n + 2 * (2 * n) * (Q // 2 + 1))          # bytes per band-matvec
     roofline = None
@@ -184,32 +271,30 @@ def main():
             "conv_share_of_step": round(conv_ms * 1e-3 * matvecs / elapsed, 3),
         }
 
-    # ------------------------------------------------------------------ cpu baseline
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(psfhat[0], b[0], sigmainv, n, nband, args.cpu_seconds, x[0])
+        cpu, parity = cpu_baseline(plan, psfhat, b, sigmainv, n, nband, args)
 
-    if rank == 0:
-        out = {
-            "metric": "PCG matvecs/sec (FFT-conv A^H A apply), 4k x 4k x 8-band cube",
-            "value": round(value, 3), "unit": "cube-matvecs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{n}x{n}x{nband}-band cube PCG (hessian_psf + Tikhonov, "
-                                   f"M = x/sigmainv, tol=0, minit=maxit={args.steps})",
-                       "nx_psf": 2 * n, "bands_per_gpu": nb, "parallelism": f"band-shard x{world}",
-                       "fast_path": plan.fast_path},
-            "band_matvecs_per_s": round(value * nband, 2),
-            "matvecs": matvecs, "backtracks": res.backtracks,
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        if cpu:
-            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    out = {
+        "metric": "PCG matvecs/sec (FFT-conv A^H A apply), 4k x 4k x 8-band cube",
+        "value": round(value, 3), "unit": "cube-matvecs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{n}x{n}x{nband}-band cube PCG (hessian_psf + Tikhonov, "
+                               f"M = x/sigmainv, tol=0, minit=maxit={args.steps})",
+                   "nx_psf": 2 * n, "bands_per_gpu": nb, "parallelism": f"band-shard x{world}",
+                   "fast_path": plan.fast_path, "allreduce_hook": bool(ctx['use_pg'])},
+        "repeats": len(times), "value_min": round(matvecs / max(times), 3),
+        "value_max": round(matvecs / min(times), 3),
+        "band_matvecs_per_s": round(value * nband, 2),
+        "matvecs": matvecs, "backtracks": res.backtracks,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+    }
+    if cpu:
+        out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+    return out
 
 
 def pmc_traffic(n, nb, dtype):
@@ -229,40 +314,239 @@ def pmc_traffic(n, nb, dtype):
     return None, None
 
 
-def cpu_baseline(psfhat_dev, b_dev, sigmainv, n, nband, seconds, x_gpu):
-    """Oracle (numpy + scipy.fft, all host cores) on ONE band of the cube: per-band PCG is
-    the same arithmetic per band as the cube PCG; cube-matvecs/s = band rate / nband."""
+# ------------------------------------------------------------------------------ CPU leg
+def _cpu_share(args):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    if args.cpu_cores > 0:
+        return min(args.cpu_cores, avail), avail
+    # a one-GPU box's share of its host is 16 cores (the gpurun contract); never more than we may use
+    return min(16, avail), avail
+
+
+def cpu_worker(d, band, threads, iters, sigmainv):
+    """Child process of cpu_baseline: the oracle's pcg on ONE band with `threads` FFT workers."""
+    import numpy as np
+    band, threads, iters, sigmainv = int(band), int(threads), int(iters), float(sigmainv)
     from oracle import fftconv as ofc, solvers as osv
-    # scipy.fft gets SLOWER beyond ~16 workers at this size (tools/cpu_workers_sweep.py on the GPU box:
-    # 209 ms per 4096^2 band-matvec with 16 workers, 300 ms with 64, 640 ms with 256), and 16 is
-    # also the CPU share of a one-GPU box: use 16 threads and report them
-    cores = min(16, os.cpu_count() or 1)
-    psfhat = psfhat_dev.cpu().numpy()
-    b = b_dev.cpu().numpy()
-    Q = 2 * n
+    psfhat = np.load(os.path.join(d, f'psfhat{band}.npy'), mmap_mode='r')
+    psfhat = np.ascontiguousarray(psfhat)
+    b = np.load(os.path.join(d, f'b{band}.npy'))
+    Q = 2 * (psfhat.shape[1] - 1)
     xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, b.dtype)
 
     def A(v):
-        return ofc._hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, v, nthreads=cores,
+        return ofc._hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, v, nthreads=threads,
                                       sigmainv=b.dtype.type(sigmainv))
-    t0 = time.perf_counter()
-    A(b)
-    t_one = time.perf_counter() - t0
-    iters = int(max(2, min(50, seconds / max(t_one * 1.3, 1e-6))))
-    t0 = time.perf_counter()
-    osv.pcg(A, b, None, M=lambda v: v / b.dtype.type(sigmainv), tol=0.0, maxit=iters, minit=iters,
-            verbosity=0)
-    dt = time.perf_counter() - t0
-    band_rate = (iters + 1) / dt
+    y = A(b)                                            # warm-up matvec (plans, page faults) + parity vector
+    if band == 0:
+        np.save(os.path.join(d, 'Ab0.npy'), y)
+    open(os.path.join(d, f'ready{band}'), 'w').close()
+    go = os.path.join(d, 'go')
+    while not os.path.exists(go):
+        time.sleep(0.005)
+    t0 = time.time()
+    osv.pcg(A, b, None, M=lambda v: v / b.dtype.type(sigmainv), tol=0.0, maxit=iters, minit=iters, verbosity=0)
+    t1 = time.time()
+    with open(os.path.join(d, f'done{band}.json.tmp'), 'w') as f:
+        json.dump({"t0": t0, "t1": t1}, f)
+    os.replace(os.path.join(d, f'done{band}.json.tmp'), os.path.join(d, f'done{band}.json'))
+    return 0
+
+
+def cpu_baseline(plan, psfhat_dev, b_dev, sigmainv, n, nband, args):
+    """All `nband` bands of the cube solved CONCURRENTLY by the oracle (numpy + scipy.fft), one child
+    process per band with cores/nband FFT workers each -- the cube PCG's arithmetic per band is the
+    per-band PCG's, and the reference runs bands side by side (pcg.py:320-356) -- for a bounded number of
+    iterations.  Cube rate = (iterations + 1) / wall time of the slowest band.  Also returns the parity
+    object: one band-matvec of the oracle against the GPU plan on the same vector."""
+    import numpy as np
+    import torch
     import scipy
-    return {"value": round(band_rate / nband, 4), "unit": "cube-matvecs/s", "cores": cores,
-            "kind": "port",
-            "sample": f"oracle pcg (numpy + scipy.fft {scipy.__version__} workers={cores}) on 1 of "
-                      f"{nband} bands, {iters} iterations = {iters + 1} matvecs in {dt:.1f} s; "
-                      f"cube rate = band rate / {nband}; host has {os.cpu_count()} cores, "
-                      f"scipy.fft is fastest at ~16 workers for this size",
-            "band_matvecs_per_s": round(band_rate, 3)}
+    cores, avail = _cpu_share(args)
+    threads = max(1, cores // nband)
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else None
+    d = tempfile.mkdtemp(prefix='pfb_bench_', dir=base)
+    procs = []
+    try:
+        for k in range(nband):
+            np.save(os.path.join(d, f'psfhat{k}.npy'), psfhat_dev[k].cpu().numpy())
+            np.save(os.path.join(d, f'b{k}.npy'), b_dev[k].cpu().numpy())
+        # one matvec costs ~ t_one with `threads` workers: calibrate on the host before choosing the count
+        t_one = _calibrate_matvec(d, threads, sigmainv)
+        iters = int(max(2, min(50, args.cpu_seconds / max(t_one * 1.5, 1e-6))))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        for k in range(nband):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', d, str(k),
+                                           str(threads), str(iters), repr(float(sigmainv))], env=env))
+        deadline = time.time() + 600
+        while not all(os.path.exists(os.path.join(d, f'ready{k}')) for k in range(nband)):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+                raise RuntimeError("cpu_baseline worker failed during setup")
+            time.sleep(0.02)
+        open(os.path.join(d, 'go'), 'w').close()
+        for p in procs:
+            if p.wait(timeout=1200) != 0:
+                raise RuntimeError("cpu_baseline worker failed")
+        marks = [json.load(open(os.path.join(d, f'done{k}.json'))) for k in range(nband)]
+        wall = max(m["t1"] for m in marks) - min(m["t0"] for m in marks)
+        rate = (iters + 1) / wall
+        # parity: the same band-0 matvec on the GPU
+        ref = np.load(os.path.join(d, 'Ab0.npy'))
+        got = plan.apply(b_dev[0:1].contiguous(), sigmainv=sigmainv, band0=0)[0].cpu().numpy()
+        relerr = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref).max())
+        tol = 1e-5 if ref.dtype == np.float32 else 1e-12
+        parity = {"conv_relerr": relerr, "tol": tol, "ok": bool(relerr <= tol),
+                  "what": f"max|gpu - cpu| / max|cpu| of hessian_psf on band 0 of the dirty cube ({n}x{n}, "
+                          f"{'fp32' if ref.dtype == np.float32 else 'fp64'}), oracle/fftconv._hessian_psf_slice vs pfb_psfconv_apply"}
+        cpu = {"value": round(rate, 4), "unit": "cube-matvecs/s", "cores": threads * nband, "kind": "port",
+               "sample": f"oracle pcg (numpy + scipy.fft {scipy.__version__}) on all {nband} bands concurrently, "
+                         f"{nband} processes x {threads} FFT workers, {iters} iterations = {iters + 1} cube-matvecs "
+                         f"in {wall:.1f} s; host has {os.cpu_count()} logical cores, {avail} usable by this process",
+               "band_matvecs_per_s": round(rate * nband, 3)}
+        return cpu, parity
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _calibrate_matvec(d, threads, sigmainv):
+    import numpy as np
+    from oracle import fftconv as ofc
+    psfhat = np.load(os.path.join(d, 'psfhat0.npy'))
+    b = np.load(os.path.join(d, 'b0.npy'))
+    Q = 2 * (psfhat.shape[1] - 1)
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, b.dtype)
+    ofc._hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, b, nthreads=threads, sigmainv=b.dtype.type(sigmainv))
+    t0 = time.perf_counter()
+    ofc._hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, b, nthreads=threads, sigmainv=b.dtype.type(sigmainv))
+    # with all bands running side by side the memory system is shared: expect ~1.5x this
+    return time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------ primal-dual (C4)
+def bench_pd(ctx):
+    """BASELINE config #4: primal_dual_optimised (primal_dual.py:91-180) on 2048^2 x 4 bands with the
+    dictionary self + db1..db4, 3 levels; grad(x) = psf_convolve_cube(x) - dirty as in
+    workers/spotless.py:259-260.  One step = one primal-dual iteration."""
+    import torch
+    import torch.distributed as dist
+    args, world, rank, device = ctx['args'], ctx['world'], ctx['rank'], ctx['device']
+    if world > 1:
+        raise SystemExit("--workload pd is a one-GPU workload (config #4)")
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    from pfb_clean_amd.operators.psi import Psi
+    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised
+
+    n = args.size or 2048
+    nband = args.bands or 4
+    dtype = torch.float32 if args.dtype == 'f32' else torch.float64
+    bases = ['self', 'db1', 'db2', 'db3', 'db4']
+    nlevel = 3
+    Q = 2 * n
+    psfhat = torch.stack([synth_band(k, nband, n, n, dtype, device) for k in range(nband)])
+    plan = PsfConvPlan(psfhat, n, n, Q)
+    model = torch.stack([synth_model(k, n, n, dtype, device) for k in range(nband)])
+    dirty = plan.apply(model).clone()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1420)
+    dirty += 1e-3 * torch.randn(dirty.shape, dtype=dtype, device=device, generator=gen)
+    del model
+    psi = Psi(nband, n, n, bases, nlevel, 1, dtype=dtype)
+    nbasis = len(bases)
+    conv_out = torch.empty_like(dirty)
+
+    def grad(v):
+        return plan.apply(v, out=conv_out) - dirty          # spotless.py:259-260 (the subtraction is a torch op)
+    w = torch.ones((nbasis, psi.Nymax, psi.Nxmax), dtype=dtype, device=device)
+    lam = 1e-3 * float(dirty.abs().max().item())
+    L = 1.0                                                   # sum_band psf peaks at 1 => ||A^H A|| ~ 1
+
+    def run(iters):
+        x = torch.zeros_like(dirty)
+        v = torch.zeros((nband, nbasis, psi.Nymax, psi.Nxmax), dtype=dtype, device=device)
+        return primal_dual_optimised(x, v, lam, psi.hdot, psi.dot, L, None, w, None, grad, nu=nbasis,
+                                     tol=0.0, maxit=iters, positivity=1, verbosity=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    times, _ = _timed_regions(lambda: run(args.steps), barrier, args.repeats, world, device)
+    elapsed = _median(times)
+    value = args.steps / elapsed
+    s = 4 if dtype == torch.float32 else 8
+    N = n * n
+    coef = nbasis * psi.Nymax * psi.Nxmax
+    # algorithmic bytes of one iteration (SURVEY 8d): analysis reads the image once per basis and writes the
+    # coefficients, synthesis the reverse with ONE image write, the dual update reads v, vp, w and writes
+    # v, vp, the convolution B_alg per band, the gradient subtraction 3 N, the primal update reads xp,
+    # xout, g and writes x
+    balg = s * nband * ((N + coef) + (coef + N) + 4 * coef + (2 * N + 2 * (2 * n) * (Q // 2 + 1)) + 3 * N + 4 * N) \
+        + s * coef
+    achieved = balg / elapsed * args.steps / 1e9
+    roofline = {"bound": "hbm", "kernel": "primal-dual iteration (psi^H, dual update, psi, PSF conv, primal update)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_iteration": balg, "ms_per_iteration": round(1e3 * elapsed / args.steps, 4),
+                "timing": "wall clock of the timed region / steps (the iteration is several launches; the host "
+                          "reads three scalars per iteration)"}
+    out = {
+        "metric": "primal-dual iterations/sec (psi/psi^H + L1 prox + PSF-conv gradient), 2k x 2k x 4-band (BASELINE config 4)",
+        "value": round(value, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{n}x{n}x{nband}-band primal_dual_optimised, bases {'+'.join(bases)}, {nlevel} levels, "
+                               f"positivity=1, tol=0, maxit={args.steps}",
+                   "coeff_shape": [nband, nbasis, psi.Nymax, psi.Nxmax], "fast_path": plan.fast_path},
+        "repeats": len(times), "value_min": round(args.steps / max(times), 3), "value_max": round(args.steps / min(times), 3),
+        "roofline": roofline, "cpu_baseline": None,
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_pd(psfhat, dirty, lam, L, n, nband, bases, nlevel, args)
+        if out["cpu_baseline"]:
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    return out
+
+
+def cpu_baseline_pd(psfhat_dev, dirty_dev, lam, L, n, nband, bases, nlevel, args):
+    """The oracle's primal_dual_optimised (numpy wavelets + scipy.fft convolution) on the same cube for a
+    bounded number of iterations, scipy.fft with the process's CPU share."""
+    import numpy as np
+    import scipy
+    from oracle import fftconv as ofc, solvers as osv, wavelets as owv
+    cores, avail = _cpu_share(args)
+    psfhat = psfhat_dev.cpu().numpy()
+    dirty = dirty_dev.cpu().numpy()
+    Q = 2 * n
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, dirty.shape, dirty.dtype)
+    psi = owv.Psi(nband, n, n, bases, nlevel)
+    nbasis = len(bases)
+
+    def grad(v):
+        return ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, v, nthreads=cores) - dirty
+    w = np.ones((nbasis, psi.Nymax, psi.Nxmax), dtype=dirty.dtype)
+
+    def run(iters):
+        x = np.zeros_like(dirty)
+        v = np.zeros((nband, nbasis, psi.Nymax, psi.Nxmax), dtype=dirty.dtype)
+        t0 = time.perf_counter()
+        osv.primal_dual_optimised(x, v, lam, psi.hdot, psi.dot, L, None, w, None, grad, nu=nbasis, tol=0.0,
+                                  maxit=iters, positivity=1, verbosity=0)
+        return time.perf_counter() - t0
+    t1 = run(1)
+    iters = int(max(1, min(20, args.cpu_seconds / max(t1, 1e-6))))
+    dt = run(iters)
+    return {"value": round(iters / dt, 4), "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"oracle primal_dual_optimised (numpy wavelets, scipy.fft {scipy.__version__} workers={cores}) on the "
+                      f"same {n}x{n}x{nband} cube, {iters} iterations in {dt:.1f} s; the numpy wavelet passes are "
+                      f"single-threaded; host has {os.cpu_count()} logical cores, {avail} usable by this process"}
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -38,6 +38,7 @@ int pow2_rows_per_wg(const pfb_conv_plan* p);
 int pow2_nblocks(const pfb_conv_plan* p);
 int pow2_nvb(const pfb_conv_plan* p);
 int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st);
+int pow2_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st);
 
 struct ConvDims {
     int nx, ny, P, Q, M, VB, nvb;
@@ -549,6 +550,11 @@ int pfb_psfconv_set_psfhat(pfb_conv_plan* p, const void* psfhat, void* stream) {
 
 int pfb_psfconv_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, void* stream) {
     PFB_REQUIRE(p && psf, PFB_ERR_INVALID, "set_psf: null argument");
+    if (p->fast) {             // power-of-two plan: the fast path's own row / column kernels (fftconv_pow2.hip)
+        int rc = pow2_set_psf(p, psf, psfhat_out, as_stream(stream));
+        if (rc == PFB_OK) p->have_psf = 1;
+        return rc;
+    }
     const size_t csz = p->dtype == PFB_F32 ? 8 : 16;
     const size_t lds_need = 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
     PFB_REQUIRE(lds_need <= 160 * 1024, PFB_ERR_UNSUPPORTED,

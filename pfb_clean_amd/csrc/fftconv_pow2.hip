@@ -48,6 +48,27 @@
 
 namespace pfb {
 
+// ---- diagnostic build (make stamp: -DPFB_STAMP=1 -> libpfb_hip_stamp.so; never in the product): thread 0 of
+// every workgroup of the three persistent kernels records the 100 MHz wall clock at its phase boundaries for
+// the tiles / items PFB_STAMP_FIRST .. +PFB_STAMP_ITS of its loop; tools/stamp_report.py turns the buffer into
+// a per-phase time table.  Layout: buf[((kernel * 1024 + workgroup) * PFB_STAMP_ITS + it) * 16 + slot].
+#ifndef PFB_STAMP
+#define PFB_STAMP 0
+#endif
+#if PFB_STAMP
+#define PFB_STAMP_ITS 4
+#define PFB_STAMP_FIRST 2
+static __device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP(KID, it, slot)                                                                              \
+    do {                                                                                                  \
+        const unsigned _si = (unsigned)((it) - PFB_STAMP_FIRST);                                          \
+        if (threadIdx.x == 0 && g_stamp_buf && _si < PFB_STAMP_ITS && blockIdx.x < 1024)                  \
+            g_stamp_buf[(((size_t)(KID) * 1024 + blockIdx.x) * PFB_STAMP_ITS + _si) * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(KID, it, slot) do { (void)(it); } while (0)
+#endif
+
 // elements per thread: the column kernel favours occupancy (small register arrays, it
 // is the HBM-streaming kernel), the row kernels favour few threads per row so that 8
 // rows (64-byte transposed pieces) fit one 1024-thread workgroup.
@@ -126,6 +147,8 @@ __device__ __forceinline__ P* opaque(P* p) {
 struct FastDims {
     int nx, ny, M;              // M = ny (packed length), nv = M + 1 columns
     size_t T_band, psf_band;
+    size_t xpitch, xband;       // forward row kernels: elements between rows / bands of x and beam (ny, nx ny for
+                                // an image cube; the PSFHAT producer reads quadrants of the (P, Q) PSF: pitch Q)
 };
 
 // ---------------------------------------------------------------- psfhat re-layout
@@ -161,6 +184,30 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
             block_of_bin(v, L, nvb, &blk, &c);
             psf_l[(size_t)band * psf_band + (((size_t)blk * 2 + (u & 1)) * H + (u >> 1)) * nvb + c] = tile[tx][r];
         }
+    }
+}
+
+// psfhat[band][u][v] = psf_l[band][blk][u & 1][u >> 1][c]: the reference's layout back out of the plan's
+template <typename T>
+__global__ void k_unrelayout_psf_pow2(const cplx<T>* __restrict__ psf_l, cplx<T>* __restrict__ psfhat,
+                                      int P, int nv, int L, int nvb, size_t psf_band) {
+    __shared__ cplx<T> tile[32][33];
+    const int band = blockIdx.z;
+    const int u0 = blockIdx.y * 32, v0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int H = P / 2;
+    for (int r = ty; r < 32; r += 8) {
+        const int v = v0 + r, u = u0 + tx;
+        if (u < P && v < nv) {
+            int blk, c;
+            block_of_bin(v, L, nvb, &blk, &c);
+            tile[tx][r] = psf_l[(size_t)band * psf_band + (((size_t)blk * 2 + (u & 1)) * H + (u >> 1)) * nvb + c];
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int u = u0 + r, v = v0 + tx;
+        if (u < P && v < nv) psfhat[((size_t)band * P + u) * nv + v] = tile[r][tx];
     }
 }
 
@@ -302,6 +349,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     __syncthreads();                                            // twiddle table visible
 #pragma unroll 1
     for (int it = 0; it < niter; ++it, item += stride) {
+        STAMP(1, it, 0);
         const bool active = item < nitems;
         cplx<T>* col = col_of(active ? item : 0);
         const cplx<T>* pe = psf_of(active ? item : 0);
@@ -329,16 +377,20 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 }
             }
         }
+        STAMP(1, it, 1);
         // ---- even bins
         F::template runN<false, NVB, 0>(vv, lds, t, ltw);
+        STAMP(1, it, 2);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
             for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
+        STAMP(1, it, 3);
 #pragma unroll
         for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
         F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+        STAMP(1, it, 4);
         cplx<T> ev[NVB][E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -347,12 +399,15 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         }
         // ---- odd bins
         F::template runN<false, NVB, 0>(vv, lds, t, ltw);
+        STAMP(1, it, 5);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
             for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
+        STAMP(1, it, 6);
         F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+        STAMP(1, it, 7);
         if (active) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -361,6 +416,74 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 for (int c = 0; c < NVB; ++c) o.c[c] = ev[c][j] + mulc(vv[c][j], tw[j]);
                 storeb<T, NVB>(col + NVB * TPB * j, o);
             }
+        }
+        STAMP(1, it, 8);
+    }
+}
+
+// ------------------------------------------------- column, forward only: the PSFHAT producer
+// psfhat = r2c(ifftshift(psf)) (gridder.py:712-714) on the fast path's own kernels.  The (P, Q) = (2 nx, 2 ny)
+// shifted PSF s is cut into its four (nx, ny) quadrants s_ab (a: top / bottom, b: left / right); the PRUNED
+// forward row kernel turns each into a half spectrum T_ab (same layout as the convolution's T), and with
+// sigma = (-1)^v (+ for the even-bin blocks, - for the odd-bin blocks)
+//     R_top = T_00 + sigma T_01,   R_bot = T_10 + sigma T_11            (un-pruned row transform of length Q)
+//     psfhat[2k]   = FFT_nx(R_top + R_bot)[k]
+//     psfhat[2k+1] = FFT_nx((R_top - R_bot) .* w_P^n)[k]                 (un-pruned column transform of length P)
+// written straight into the plan's psf_l[blk][pu][mu][c] layout.
+template <typename T, int H, int E>
+__global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), (E >= 16 ? 2 : FastCfg<T>::WCOL))
+k_col_fwd_pow2(const cplx<T>* __restrict__ Tq, cplx<T>* __restrict__ psf_b,
+               const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
+               int nblk, int nbe, size_t T_band) {
+    using F = RegFft<T, H, E>;
+    constexpr int TPB = F::TPB;
+    constexpr int NVB = FastCfg<T>::NVB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
+    cplx<T>* lds = reinterpret_cast<cplx<T>*>(smem) + (size_t)g * (NVB * F::LDS_ELEMS);
+    const int blk = blockIdx.x * col_groups<H, E>() + g;
+    const bool active = blk < nblk;
+    const size_t b = active ? blk : 0;
+    const T sg = b >= (size_t)nbe ? T(-1) : T(1);
+    const cplx<T>* c00 = Tq + (b * (size_t)H + t) * NVB;
+    cplx<T> ve[NVB][E], vo[NVB][E];
+    {
+        const cplx<T>* tw2 = twP + t;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const Blk<T, NVB> a00 = loadb<T, NVB>(c00 + NVB * TPB * j);
+            const Blk<T, NVB> a01 = loadb<T, NVB>(c00 + T_band + NVB * TPB * j);
+            const Blk<T, NVB> a10 = loadb<T, NVB>(c00 + 2 * T_band + NVB * TPB * j);
+            const Blk<T, NVB> a11 = loadb<T, NVB>(c00 + 3 * T_band + NVB * TPB * j);
+            const cplx<T> w = tw2[TPB * j];
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) {
+                const cplx<T> top = a00.c[c] + sg * a01.c[c], bot = a10.c[c] + sg * a11.c[c];
+                ve[c][j] = top + bot;
+                vo[c][j] = (top - bot) * w;
+            }
+        }
+    }
+    cplx<T>* pe = psf_b + (b * (2 * (size_t)H) + t) * NVB;
+    cplx<T>* po = pe + (size_t)H * NVB;
+    F::template runN<false, NVB>(ve, lds, t, ptw);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            Blk<T, NVB> o;
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) o.c[c] = ve[c][j];
+            storeb<T, NVB>(pe + NVB * TPB * j, o);
+        }
+    }
+    F::template runN<false, NVB>(vo, lds, t, ptw);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            Blk<T, NVB> o;
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) o.c[c] = vo[c][j];
+            storeb<T, NVB>(po + NVB * TPB * j, o);
         }
     }
 }
@@ -433,7 +556,7 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
     cplx<T>* lds = lds0 + (size_t)g * STRIDE;
     const int i0 = blockIdx.x * G;
     const int bl = blockIdx.y, band = band0 + bl;
-    const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+    const size_t rowoff = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
     const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
     const V2* br = beam ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
     cplx<T>* Tb = Tw + (size_t)band * d.T_band;
@@ -547,7 +670,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     {
         const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
         const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
-        const size_t off = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+        const size_t off = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
         const V2* xr = reinterpret_cast<const V2*>(x + off) + t;
 #pragma unroll
         for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
@@ -558,7 +681,8 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
         }
     }
     __syncthreads();                                    // tables visible
-    for (;;) {
+    for (int sit = 0;; ++sit) {
+        STAMP(0, sit, 0);
         const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
         const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
         cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
@@ -575,7 +699,9 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
                 vv[1][j] = vv[0][j] * ltm[t + TPB * j];          // z .* w_M^n  (odd bins)
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(0, sit, 1);
             F::template runN<false, 2>(vv, lds, t, ltw);
+            STAMP(0, sit, 2);
         }
         {   // fresh index: nothing thread-derived stays live (and gets spilled) across the FFT
             const int tid = launder((int)threadIdx.x);
@@ -586,20 +712,22 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[0][j];
             // next tile's rows: in flight during both post-processing sweeps
             const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
-            const V2* xr = reinterpret_cast<const V2*>(x + ((size_t)bln * d.nx + (i0n + g)) * d.ny) + t;
+            const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
 #pragma unroll
             for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
             __syncthreads();
         }
+        STAMP(0, sit, 3);
         {
             const int tid = launder((int)threadIdx.x);
             fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
         }
+        STAMP(0, sit, 4);
         if constexpr (BEAM) {           // the next tile's beam rows: requested once the even-bin registers are free
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB;
             const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
-            const V2* br = reinterpret_cast<const V2*>(beam + ((size_t)bln * d.nx + (i0n + g)) * d.ny) + t;
+            const V2* br = reinterpret_cast<const V2*>(beam + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
 #pragma unroll
             for (int j = 0; j < E; ++j) ba[j] = br[TPB * j];
         }
@@ -611,9 +739,12 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
 #pragma unroll
             for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[1][j];
             __syncthreads();
+            STAMP(0, sit, 5);
             fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            STAMP(0, sit, 6);
             __syncthreads();                                     // rows free for the next transform
         }
+        STAMP(0, sit, 7);
         if (vbn == vb) break;
         vb = vbn;
     }
@@ -901,7 +1032,8 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
-    for (;;) {
+    for (int sit = 0;; ++sit) {
+        STAMP(2, sit, 0);
         const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
         int bln, i0n;
         tile(vbn, bln, i0n);
@@ -913,11 +1045,16 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
             __syncthreads();
+            STAMP(2, sit, 1);
             inv_scatter<T, L, E, 0>(y, lds0 + (size_t)rr * P::STRIDE, bi);
+            STAMP(2, sit, 2);
             inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
             __syncthreads();
+            STAMP(2, sit, 3);
             inv_build<T, L, E, 0>(lds, ltm, wq1, t, vv);
+            STAMP(2, sit, 4);
             F::template run<true>(vv, lds, t, ltw);
+            STAMP(2, sit, 5);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if constexpr (P::PARK) park[j * NT + tid] = vv[j]; else ev[j] = vv[j];
@@ -930,7 +1067,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
             __syncthreads();
+            STAMP(2, sit, 6);
             inv_scatter<T, L, E, 1>(y, lds0 + (size_t)rr * P::STRIDE, bi);
+            STAMP(2, sit, 7);
             const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
             const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
             const V2* dr2 = reinterpret_cast<const V2*>(dot_with2 + rowoff) + t;
@@ -946,8 +1085,11 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             }
             inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, rr, bi, y);
             __syncthreads();
+            STAMP(2, sit, 8);
             inv_build<T, L, E, 1>(lds, ltm, wq1, t, vv);
+            STAMP(2, sit, 9);
             F::template run<true>(vv, lds, t, ltw);
+            STAMP(2, sit, 10);
         }
         // ---- z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
         {
@@ -980,6 +1122,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 }
             }
         }
+        STAMP(2, sit, 11);
         if (vbn == vb) break;
         vb = vbn; bl = bln; i0 = i0n;
     }
@@ -996,6 +1139,21 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
 }
 
 #endif  // PFB_POW2_REST
+
+#if PFB_STAMP
+#if PFB_POW2_COL
+int pow2_col_set_stamp(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? PFB_OK : PFB_ERR_HIP;
+}
+#endif
+#if PFB_POW2_REST
+int pow2_col_set_stamp(unsigned long long* buf);
+int pow2_set_stamp(unsigned long long* buf) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) != hipSuccess) return PFB_ERR_HIP;
+    return pow2_col_set_stamp(buf);
+}
+#endif
+#endif
 
 // size switch helper
 #define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
@@ -1016,6 +1174,7 @@ struct FastTables {            // device tables owned by the plan (stored behind
 // the column object's entry points (defined under PFB_POW2_COL below)
 int pow2_col_set_attr(int dtype, int H);
 int pow2_col_launch(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st);
+int pow2_col_fwd_launch(pfb_conv_plan* p, const FastTables* ft, const void* Tq, int band, hipStream_t st);
 
 #if PFB_POW2_REST
 template <typename T, int N, int E>
@@ -1189,6 +1348,56 @@ int pow2_set_psfhat(pfb_conv_plan* p, const void* psfhat, hipStream_t st) {
     return p->dtype == PFB_F32 ? set_psfhat_t<float>(p, psfhat, st) : set_psfhat_t<double>(p, psfhat, st);
 }
 
+template <typename T, int L>
+static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, void* Tbuf, int band0, int nb, const void* x,
+                           const void* beam, size_t xpitch, size_t xband, hipStream_t st);
+
+// psfhat = r2c(ifftshift(psf)) with the fast path's own kernels (see k_col_fwd_pow2), band by band:
+// four pruned row passes over the PSF quadrants (ifftshift = which quadrant goes where), one forward column pass
+// straight into psf_l; psfhat_out (optional) receives the reference's (P, M+1) layout.  Synchronous (plan time).
+template <typename T>
+static int set_psf_t(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st) {
+    const FastTables* ft = (const FastTables*)p->fast_tables;
+    const int nx = p->nx, ny = p->ny, P = p->P, Q = p->Q, L = ny / 2;
+    void* Tq = nullptr;
+    if (hipMalloc(&Tq, sizeof(cplx<T>) * 4 * p->T_elems_per_band) != hipSuccess) {
+        set_error("pow2_set_psf: device allocation failed (%zu B)", sizeof(cplx<T>) * 4 * p->T_elems_per_band);
+        return PFB_ERR_ALLOC;
+    }
+    int rc = PFB_OK;
+    for (int band = 0; band < p->nband && rc == PFB_OK; ++band) {
+        const T* pb = (const T*)psf + (size_t)band * P * Q;
+        for (int q = 0; q < 4; ++q) {
+            // quadrant (a, b) of the SHIFTED PSF = quadrant (1 - a, 1 - b) of the centred one
+            const int a = q >> 1, b = q & 1;
+            const T* src = pb + (size_t)((1 - a) * nx) * Q + (size_t)(1 - b) * ny;
+            switch (L) {
+#define X(NN) case NN: launch_row_fwd<T, NN>(p, ft, Tq, q, 1, src, nullptr, (size_t)Q, (size_t)0, st); break;
+                PFB_POW2_SIZES(X)
+#undef X
+                default: set_error("pow2_set_psf: unsupported ny"); rc = PFB_ERR_UNSUPPORTED; break;
+            }
+        }
+        if (rc == PFB_OK) rc = pow2_col_fwd_launch(p, ft, Tq, band, st);
+    }
+    if (rc == PFB_OK && psfhat_out) {
+        const int nv = p->M + 1;
+        dim3 grid((nv + 31) / 32, (P + 31) / 32, p->nband);
+        hipLaunchKernelGGL((k_unrelayout_psf_pow2<T>), grid, dim3(256), 0, st, (const cplx<T>*)p->psf_l,
+                           (cplx<T>*)psfhat_out, P, nv, L, FastCfg<T>::NVB, p->psf_elems_per_band);
+    }
+    if (rc == PFB_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        set_error("pow2_set_psf: kernel launch failed");
+        rc = PFB_ERR_HIP;
+    }
+    (void)hipFree(Tq);
+    return rc;
+}
+
+int pow2_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st) {
+    return p->dtype == PFB_F32 ? set_psf_t<float>(p, psf, psfhat_out, st) : set_psf_t<double>(p, psf, psfhat_out, st);
+}
+
 #endif  // PFB_POW2_REST
 
 #if PFB_POW2_COL
@@ -1247,6 +1456,8 @@ static int col_set_attr_t(int H) {
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false>),            \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_fwd_pow2<T, NN, ecol<T, NN>()>),                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -1270,17 +1481,46 @@ static int col_launch_t(pfb_conv_plan* p, const FastTables* ft, int band0, int n
 int pow2_col_launch(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, hipStream_t st) {
     return p->dtype == PFB_F32 ? col_launch_t<float>(p, ft, band0, nb, st) : col_launch_t<double>(p, ft, band0, nb, st);
 }
+// PSFHAT producer: the four quadrant spectra in Tq (slots of T_elems_per_band) -> psf_l of `band`
+template <typename T, int H>
+static void launch_col_fwd(pfb_conv_plan* p, const FastTables* ft, const void* Tq, int band, hipStream_t st) {
+    constexpr int E = ecol<T, H>();
+    using F = RegFft<T, H, E>;
+    constexpr int GC = col_groups<H, E>();
+    constexpr int NVB = FastCfg<T>::NVB;
+    const int L = p->ny / 2;
+    const int nblk = fast_nblocks(L, NVB), nbe = (L + NVB) / NVB;
+    const size_t lds = sizeof(cplx<T>) * (size_t)GC * NVB * F::LDS_ELEMS;
+    hipLaunchKernelGGL((k_col_fwd_pow2<T, H, E>), dim3((nblk + GC - 1) / GC), dim3(GC * F::TPB), lds, st,
+                       (const cplx<T>*)Tq, (cplx<T>*)p->psf_l + (size_t)band * p->psf_elems_per_band,
+                       (const cplx<T>*)p->twP, (const cplx<T>*)ft->ptw_col, nblk, nbe, p->T_elems_per_band);
+}
+template <typename T>
+static int col_fwd_launch_t(pfb_conv_plan* p, const FastTables* ft, const void* Tq, int band, hipStream_t st) {
+    switch (p->nx) {
+#define X(NN) case NN: launch_col_fwd<T, NN>(p, ft, Tq, band, st); break;
+        PFB_POW2_SIZES(X)
+#undef X
+        default: set_error("pow2_set_psf: unsupported nx"); return PFB_ERR_UNSUPPORTED;
+    }
+    return PFB_OK;
+}
+int pow2_col_fwd_launch(pfb_conv_plan* p, const FastTables* ft, const void* Tq, int band, hipStream_t st) {
+    return p->dtype == PFB_F32 ? col_fwd_launch_t<float>(p, ft, Tq, band, st) : col_fwd_launch_t<double>(p, ft, Tq, band, st);
+}
 #endif  // PFB_POW2_COL
 
 #if PFB_POW2_REST
 
+// Tbuf: the half-spectrum buffer to fill (the plan's T, or the PSFHAT producer's quadrant scratch: `band0`
+// is then the slot); xpitch / xband: elements between rows / bands of x (and beam)
 template <typename T, int L>
-static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, int nb, const void* x,
-                           const void* beam, hipStream_t st) {
+static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, void* Tbuf, int band0, int nb, const void* x,
+                           const void* beam, size_t xpitch, size_t xband, hipStream_t st) {
     constexpr int E = RowCfg<T, L, false>::E;
     using F = RegFft<T, L, E, RowCfg<T, L, false>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, false>::GMAX>();
-    FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
+    FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band, xpitch, xband};
     if constexpr (FwdP<T, L>::OK) {
         if (ft->fwd_persistent) {
             using FP = FwdP<T, L>;
@@ -1290,18 +1530,18 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, int band0, in
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
             if (beam)
                 hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, true>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
-                                   (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)ft->twM,
+                                   (const T*)beam, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,
                                    (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
             else
                 hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, false>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
-                                   (const T*)nullptr, (cplx<T>*)p->T, (const cplx<T>*)ft->twM,
+                                   (const T*)nullptr, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,
                                    (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
             return;
         }
     }
     const size_t lds = sizeof(cplx<T>) * (size_t)G * (F::LDS_ELEMS + 4);
     hipLaunchKernelGGL((k_row_fwd_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
-                       (const T*)x, (const T*)beam, (cplx<T>*)p->T, (const cplx<T>*)p->twQ,
+                       (const T*)x, (const T*)beam, (cplx<T>*)Tbuf, (const cplx<T>*)p->twQ,
                        (const cplx<T>*)ft->twM, (const cplx<T>*)ft->ptw_row, d, band0);
 }
 
@@ -1312,7 +1552,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     constexpr int E = RowCfg<T, L, true>::E;
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
-    FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band};
+    FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band, (size_t)p->ny, (size_t)p->nx * p->ny};
     if constexpr (InvP<T, L, E>::OK) {
         // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
         const bool plain_dots = !dot_with || (dot_with == x);
@@ -1352,7 +1592,7 @@ static int apply_t(pfb_conv_plan* p, int band0, int nb, const void* x, const voi
     const int H = p->nx, L = p->ny / 2;
     prof_mark(p, st, 0);
     switch (L) {
-#define X(NN) case NN: launch_row_fwd<T, NN>(p, ft, band0, nb, x, beam, st); break;
+#define X(NN) case NN: launch_row_fwd<T, NN>(p, ft, p->T, band0, nb, x, beam, (size_t)p->ny, (size_t)p->nx * p->ny, st); break;
         PFB_POW2_SIZES(X)
 #undef X
         default: set_error("pow2_apply: unsupported ny"); return PFB_ERR_UNSUPPORTED;
@@ -1379,3 +1619,8 @@ int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* b
 #endif  // PFB_POW2_REST
 
 }  // namespace pfb
+
+#if PFB_STAMP && PFB_POW2_REST
+// diagnostic build only: buf = 3 * 1024 * PFB_STAMP_ITS * 16 device uint64 (NULL switches the stamps off)
+extern "C" int pfb_debug_set_stamps(void* buf) { return pfb::pow2_set_stamp((unsigned long long*)buf); }
+#endif

@@ -54,7 +54,13 @@ def _embed_grid(nx, ny, nx_psf, ny_psf, rdtype):
 
 class PsfConvPlan:
     """Owns the device plan (twiddles, re-laid-out psfhat, spectrum workspace) for one
-    psfhat cube.  psfhat: (nband, nx_psf, nyo2) or (nx_psf, nyo2) complex."""
+    psfhat cube.  psfhat: (nband, nx_psf, nyo2) or (nx_psf, nyo2) complex.
+
+    A plan is single-owner in the C-ABI (one stream and one host thread at a time: its spectrum
+    workspace, fused-dot partials and profiling slots are per plan).  plan_for() hands the SAME plan to
+    every host thread that presents the same psfhat (the reference's dask threads do, pcg.py:346-356), so
+    the Python layer serialises: `lock` is held for the enqueue of an apply and for a whole fused solve,
+    and a caller on a different stream than the previous user first waits for that stream's work."""
 
     def __init__(self, psfhat, nx, ny, lastsize):
         lib = _lib.load()
@@ -75,6 +81,7 @@ class PsfConvPlan:
         self.device = ph.device
         self._lib = lib
         self._h = C.c_void_p()
+        self.lock = threading.RLock()
         # Arbitrary sizes on the power-of-two kernels: the same image-space PSF is re-gridded
         # (pfb_psfhat_regrid) onto nx_psf2 = 2 nx2, ny_psf2 = 2 ny2 with nx2, ny2 the next powers
         # of two, images are zero-padded into (nx2, ny2) buffers and results cropped.  Identical
@@ -151,6 +158,7 @@ class PsfConvPlan:
             return (plan, ph) if want_psfhat else plan
         self = cls.__new__(cls)
         self.embed = None
+        self.lock = threading.RLock()
         self.nband, self.nx_psf, self.lastsize = (int(v) for v in p.shape)
         self.nyo2 = self.lastsize // 2 + 1
         self.nx, self.ny = int(nx), int(ny)
@@ -201,10 +209,10 @@ class PsfConvPlan:
         if dot_with is not None:
             dot_with = dot_with.contiguous()
         if self.embed is not None:
-            # padded input / output buffers are kept per band count: the margins of the input buffer are
-            # written once (zeros) and never touched again, so a call costs one copy in and one copy out
+            # padded input / output buffers are kept per (band count, host thread): the margins of the input
+            # buffer are written once (zeros) and never touched again, so a call costs one copy in and one out
             cache = self.__dict__.setdefault('_pad_cache', {})
-            key = (nb, x3.device)
+            key = (nb, x3.device, threading.get_ident())
             if key not in cache:
                 cache[key] = (torch.zeros((nb,) + self.embed, dtype=self.rdtype, device=x3.device),
                               torch.empty((nb,) + self.embed, dtype=self.rdtype, device=x3.device))
@@ -212,15 +220,32 @@ class PsfConvPlan:
             xs[:, :self.nx, :self.ny] = x3
             bs = None if beam is None else self._pad(beam, nb)
             ds = None if dot_with is None else self._pad(dot_with if dot_with.ndim == 3 else dot_with[None], nb)
-        else:
-            xs, bs, ds, os_ = x3, beam, dot_with, out3
-        _lib.check(self._lib.pfb_psfconv_apply(
-            self._h, int(band0), int(nb), _dev.ptr(xs), _dev.ptr(bs),
-            float(wsum) if wsum is not None else 0.0, float(sigmainv), _dev.ptr(os_),
-            _dev.ptr(ds), _dev.ptr(dot_out), _dev.stream()))
-        if self.embed is not None:
-            out3.copy_(os_[:, :self.nx, :self.ny])
+            with self.lock:
+                self._enter_stream()
+                _lib.check(self._lib.pfb_psfconv_apply(
+                    self._h, int(band0), int(nb), _dev.ptr(xs), _dev.ptr(bs),
+                    float(wsum) if wsum is not None else 0.0, float(sigmainv), _dev.ptr(os_),
+                    _dev.ptr(ds), _dev.ptr(dot_out), _dev.stream()))
+                out3.copy_(os_[:, :self.nx, :self.ny])
+            return out3[0] if squeeze else out3
+        xs, bs, ds, os_ = x3, beam, dot_with, out3
+        with self.lock:
+            self._enter_stream()
+            _lib.check(self._lib.pfb_psfconv_apply(
+                self._h, int(band0), int(nb), _dev.ptr(xs), _dev.ptr(bs),
+                float(wsum) if wsum is not None else 0.0, float(sigmainv), _dev.ptr(os_),
+                _dev.ptr(ds), _dev.ptr(dot_out), _dev.stream()))
         return out3[0] if squeeze else out3
+
+    def _enter_stream(self):
+        """Call with `lock` held: the plan's workspace is about to be used on the current stream; if the
+        previous user enqueued on a DIFFERENT stream, wait for that work first (same stream: stream order
+        already serialises the kernels)."""
+        cur = torch.cuda.current_stream()
+        last = self.__dict__.get('_last_stream')
+        if last is not None and last != cur:
+            last.synchronize()
+        self._last_stream = cur
 
     def set_profiling(self, on):
         """on: False/0 off, True/1 every apply, N > 1 every N-th apply (each timed apply puts

@@ -119,7 +119,9 @@ class _Work:
     @classmethod
     def get(cls, plan, nb):
         # per host thread: the reference may drive per-band solves from several dask threads
-        # (pcg.py:346-356); solves on different band ranges of one plan must not share scratch
+        # (pcg.py:346-356).  Solves on ONE plan are serialised by plan.lock (the plan's spectrum workspace and
+        # dot partials are single-owner); the vectors of a solve still live in a per-thread scratch so that a
+        # thread's result buffers are not overwritten by the next thread's solve
         key = (id(plan), nb, _dev.stream(), threading.get_ident())
         nbytes = _lib.load().pfb_pcg_work_bytes(plan.handle, nb)
         w = cls._cache.get(key)
@@ -172,11 +174,13 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
                 print(f"pfb_clean_amd: allreduce hook failed: {e!r}", file=sys.stderr)
                 return 1
         cb = _lib.ALLREDUCE_FN(_hook)
-    _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
-                                 _dev.ptr(beam), A.wsum if A.wsum is not None else 0.0,
-                                 A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
-                                 _backtrack_mode(backtrack), _dev.ptr(work), cb, None, C.byref(res),
-                                 _dev.stream()))
+    with plan.lock:            # a plan is single-owner (include/pfb_hip.h): one solve at a time per plan
+        plan._enter_stream()
+        _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
+                                     _dev.ptr(beam), A.wsum if A.wsum is not None else 0.0,
+                                     A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
+                                     _backtrack_mode(backtrack), _dev.ptr(work), cb, None, C.byref(res),
+                                     _dev.stream()))
     if plan.embed is not None:
         x = x[:, :plan.nx, :plan.ny].contiguous()
         r = None if r is None else r[:, :plan.nx, :plan.ny].contiguous()

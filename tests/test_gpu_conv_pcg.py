@@ -609,3 +609,89 @@ def test_pcg_degenerate_iteration_limits(amd, golden):
         tr = osv.PCGTrace()
         xo = osv.pcg(Ao, b, g['cube_x0'].copy(), M=lambda v: v / sigmainv, trace=tr, **kw)
         assert res.iters == tr.k_exit and relerr(x.cpu().numpy(), xo) < 1e-10, kw
+
+
+def test_one_plan_shared_by_concurrent_host_threads(amd, golden):
+    """plan_for() hands the SAME PsfConvPlan to every host thread that presents the same psfhat (what the
+    reference's dask threads do with one functools.partial, pcg.py:346-356).  The plan's spectrum workspace
+    and dot partials are single-owner (include/pfb_hip.h), so the Python layer serialises on plan.lock:
+    convolutions and fused solves on different band ranges from four threads, default stream and private
+    streams, must equal the sequential results bitwise."""
+    import threading
+    g = golden('pcg')
+    psfhat, b = g['psfhat'], g['b']
+    sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+    nband, nx, ny = b.shape
+    dev = torch.device('cuda')
+    ph = torch.from_numpy(psfhat).to(dev)
+    amd.psf.clear_plan_cache()
+    plan = amd.psf.plan_for(ph, nx, ny, Q)
+    assert amd.psf.plan_for(ph, nx, ny, Q) is plan
+    ops = [amd.hessian.HessianPsf(plan, nx, ny, Q, sigmainv=sigmainv, band0=k, nb=1) for k in range(nband)]
+    rhs = [torch.from_numpy(b[k:k + 1]).to(dev) for k in range(nband)]
+    rng = np.random.default_rng(5)
+    xs = [torch.from_numpy(rng.standard_normal((1, nx, ny))).to(dev) for _ in range(nband)]
+
+    def job(k):
+        y = plan.apply(xs[k], band0=k, sigmainv=0.5).clone()
+        s = amd.pcg.pcg_fused(ops[k], rhs[k], None, mdiv=sigmainv, tol=0.0, maxit=8, minit=8)[0].clone()
+        return y, s
+    seq = [job(k) for k in range(nband)]
+    for own_stream in (False, True):
+        for _ in range(3):
+            out = [None] * nband
+
+            def work(k):
+                if own_stream:
+                    with torch.cuda.stream(torch.cuda.Stream()):
+                        out[k] = job(k)
+                        torch.cuda.current_stream().synchronize()
+                else:
+                    out[k] = job(k)
+            ts = [threading.Thread(target=work, args=(k,)) for k in range(nband)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            torch.cuda.synchronize()
+            for k in range(nband):
+                assert torch.equal(out[k][0], seq[k][0]) and torch.equal(out[k][1], seq[k][1]), (own_stream, k)
+    amd.psf.clear_plan_cache()
+
+
+@pmp('n,nb', [(512, 2), (1024, 1)])
+def test_fp32_predictive_backtracking_matches_reference_loop(amd, n, nb):
+    """fp32 parity of the default line search: backtrack=True runs the PREDICTIVE search (three fused
+    scalars, beta from the predicted rho); the reference's loop recomputes <r', M r'> after every rejected step
+    (pcg.py:96-101, backtrack='exact' here).  On a bench-like fp32 problem (Poisson uv weights, noisy dirty
+    image, many rejected steps) both must take the same number of iterations and backtracking steps and give
+    the same iterates to the fp32 PCG tolerance; and both must match the fp64 oracle solve to that tolerance."""
+    rng = np.random.default_rng(420 + n)
+    P = Q = 2 * n
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    W = rng.poisson(4.0 * np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2)), size=(nb, P, Q // 2 + 1)).astype(np.float64)
+    psfhat64 = W / (nb * np.fft.irfft2(W, s=(P, Q))[:, 0, 0].max())
+    model = np.zeros((nb, n, n))
+    for _ in range(12):
+        i, j = rng.integers(n // 8, 7 * n // 8, size=2)
+        model[:, i, j] += 1 + rng.random()
+    xpad, xhat, xout = ofc.make_scratch(psfhat64.astype(np.complex128), Q, model.shape, np.float64)
+    ph128 = psfhat64.astype(np.complex128)
+    b64 = ofc.psf_convolve_cube(xpad, xhat, xout, ph128, Q, model).copy() + 1e-3 * rng.standard_normal(model.shape)
+    sigmainv = 1e-3 * np.abs(b64).max()
+    A = amd.hessian.HessianPsf(torch.from_numpy(psfhat64.astype(np.complex64)).cuda(), n, n, Q, sigmainv=sigmainv)
+    b32 = torch.from_numpy(b64.astype(np.float32)).cuda()
+    kw = dict(mdiv=sigmainv, tol=0.0, maxit=25, minit=25)
+    xp_, _, rp = amd.pcg.pcg_fused(A, b32, None, backtrack=True, **kw)
+    xe_, _, re_ = amd.pcg.pcg_fused(A, b32, None, backtrack='exact', **kw)
+    assert rp.iters == re_.iters == 25
+    assert rp.backtracks > 0, "the problem must exercise the line search"
+    scale = xe_.abs().max().item()
+    assert (xp_ - xe_).abs().max().item() < TOL_PCG[np.float32] * scale
+    assert abs(rp.backtracks - re_.backtracks) <= max(2, re_.backtracks // 10), (rp.backtracks, re_.backtracks)
+    Ao = lambda w: ofc.hessian_psf_cube(xpad, xhat, xout, None, ph128, Q, w, sigmainv=sigmainv)
+    tr = osv.PCGTrace()
+    xo = osv.pcg(Ao, b64, None, M=lambda w: w / sigmainv, tol=0.0, maxit=25, minit=25, trace=tr)
+    assert relerr(xp_.cpu().numpy(), xo) < 5 * TOL_PCG[np.float32]
+    assert relerr(xe_.cpu().numpy(), xo) < 5 * TOL_PCG[np.float32]

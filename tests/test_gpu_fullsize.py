@@ -17,52 +17,67 @@ import pytest
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
-N, NB = 4096, 8
+N = 4096
+
+# (label, image size, bands, real dtype): BASELINE C3 per-GPU cube and the C5 per-GPU shard (2 of 16 bands of the
+# 8192^2 fp64 cube, nx_psf = ny_psf = 16384: ~11 GB of plan memory)
+CONFIGS = [('c3', 4096, 8, 'float32'), ('c5', 8192, 2, 'float64')]
 
 
-@pytest.fixture(scope='module')
-def setup():
+def _tol(dt, f32, f64):
+    return f32 if dt == torch.float32 else f64
+
+
+@pytest.fixture(scope='module', params=CONFIGS, ids=[c[0] for c in CONFIGS])
+def setup(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pfb_clean_amd.operators.psf import PsfConvPlan
+    from pfb_clean_amd._lib import PfbHipError
+    _, n, nb, dtn = request.param
+    dt = getattr(torch, dtn)
     dev = torch.device('cuda')
     g = torch.Generator(device=dev).manual_seed(7)
-    P = Q = 2 * N
+    P = Q = 2 * n
     # symmetric, compact PSF per band: a 9 x 9 patch around the centre, psf[c + d] = psf[c - d]
     K = 4
-    patch = torch.rand((NB, K + 1, K + 1), generator=g, device=dev, dtype=torch.float32)
-    full = torch.zeros((NB, 2 * K + 1, 2 * K + 1), device=dev, dtype=torch.float32)
+    patch = torch.rand((nb, K + 1, K + 1), generator=g, device=dev, dtype=dt)
+    full = torch.zeros((nb, 2 * K + 1, 2 * K + 1), device=dev, dtype=dt)
     for a in range(-K, K + 1):
         for b in range(-K, K + 1):
             full[:, K + a, K + b] = patch[:, abs(a), abs(b)]
     full[:, K, K] += 90.0                       # diagonally dominant -> the operator is positive definite
-    psf = torch.zeros((NB, P, Q), device=dev, dtype=torch.float32)
+    psf = torch.zeros((nb, P, Q), device=dev, dtype=dt)
     psf[:, P // 2 - K:P // 2 + K + 1, Q // 2 - K:Q // 2 + K + 1] = full
-    plan = PsfConvPlan.from_psf(psf, N, N)
+    plan = PsfConvPlan.from_psf(psf, n, n)      # the library's own PSFHAT producer (gridder.py:712-714)
     assert plan.fast_path
     del psf
-    x = torch.randn((NB, N, N), generator=g, device=dev, dtype=torch.float32)
-    y = torch.randn((NB, N, N), generator=g, device=dev, dtype=torch.float32)
+    x = torch.randn((nb, n, n), generator=g, device=dev, dtype=dt)
+    y = torch.randn((nb, n, n), generator=g, device=dev, dtype=dt)
     yield plan, full, x, y, K
     plan.close()
+    del plan, x, y
+    torch.cuda.empty_cache()
 
 
 def test_point_source_response_is_the_psf(setup):
     plan, full, x, y, K = setup
+    nb, n = x.shape[0], x.shape[1]
     d = torch.zeros_like(x)
-    spots = [(0, 0), (N - 1, N - 1), (5, 4090), (2048, 2047), (4095, 0), (1000, 3000), (17, 17), (4000, 100)]
+    spots = [(0, 0), (n - 1, n - 1), (5, n - 6), (n // 2, n // 2 - 1), (n - 1, 0), (1000, 3000), (17, 17),
+             (n - 96, 100)][:nb]
     for b, (i0, j0) in enumerate(spots):
         d[b, i0, j0] = 1.0
     out = plan.apply(d)
     for b, (i0, j0) in enumerate(spots):
-        want = torch.zeros((N, N), device=x.device, dtype=torch.float32)
+        want = torch.zeros((n, n), device=x.device, dtype=x.dtype)
         for a in range(-K, K + 1):
             for c in range(-K, K + 1):
                 i, j = i0 + a, j0 + c
-                if 0 <= i < N and 0 <= j < N:
+                if 0 <= i < n and 0 <= j < n:
                     want[i, j] = full[b, K + a, K + c]
         err = (out[b] - want).abs().max().item()
-        assert err < 2e-5 * full[b].abs().max().item(), (b, err)
+        assert err < _tol(x.dtype, 2e-5, 1e-12) * full[b].abs().max().item(), (b, err)
 
 
 def test_linearity_and_self_adjointness(setup):
@@ -70,27 +85,31 @@ def test_linearity_and_self_adjointness(setup):
     Ax, Ay = plan.apply(x), plan.apply(y)
     comb = plan.apply(0.75 * x - 1.5 * y)
     scale = Ax.abs().max().item()
-    assert (comb - (0.75 * Ax - 1.5 * Ay)).abs().max().item() < 2e-5 * scale
+    assert (comb - (0.75 * Ax - 1.5 * Ay)).abs().max().item() < _tol(x.dtype, 2e-5, 1e-12) * scale
     lhs = torch.sum(y.double() * Ax.double()).item()
     rhs = torch.sum(Ay.double() * x.double()).item()
-    assert abs(lhs - rhs) < 1e-5 * (torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(Ax.double())).item()
+    assert abs(lhs - rhs) < _tol(x.dtype, 1e-5, 1e-12) * (torch.linalg.vector_norm(y.double()) * torch.linalg.vector_norm(Ax.double())).item()
 
 
 def test_band_subranges_match_full_launch_bitwise(setup):
     plan, full, x, y, K = setup
+    nb = x.shape[0]
     whole = plan.apply(x, sigmainv=0.25)
-    for b0, nb in ((0, 4), (4, 4), (7, 1), (2, 3)):
-        part = plan.apply(x[b0:b0 + nb], band0=b0, sigmainv=0.25)
-        assert torch.equal(part, whole[b0:b0 + nb]), (b0, nb)
+    for b0, k in ((0, 4), (4, 4), (7, 1), (2, 3), (0, 1), (1, 1)):
+        if b0 + k > nb:
+            continue
+        part = plan.apply(x[b0:b0 + k], band0=b0, sigmainv=0.25)
+        assert torch.equal(part, whole[b0:b0 + k]), (b0, k)
 
 
 def test_fused_inner_products(setup):
     from pfb_clean_amd import _lib, _dev
     plan, full, x, y, K = setup
+    nb = x.shape[0]
     out = torch.empty_like(x)
     dots = torch.zeros(3, dtype=torch.float64, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, NB, _dev.ptr(x), None, 0.0, 0.1, _dev.ptr(out),
+    _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(x), None, 0.0, 0.1, _dev.ptr(out),
                                           _dev.ptr(x), _dev.ptr(y), _dev.ptr(dots), _dev.stream()))
     od = out.double()
     want = [torch.sum(x.double() * od).item(), torch.sum(y.double() * od).item(), torch.sum(od * od).item()]
@@ -105,14 +124,54 @@ def test_fused_pcg_reduces_the_residual(setup):
     from pfb_clean_amd.operators.hessian import HessianPsf
     from pfb_clean_amd.opt.pcg import pcg_fused
     plan, full, x, y, K = setup
+    n = x.shape[1]
     sig = 0.5
-    A = HessianPsf(plan, N, N, 2 * N, sigmainv=sig)
+    A = HessianPsf(plan, n, n, 2 * n, sigmainv=sig)
     b = A(x)                                            # consistent right-hand side, solution x
-    sol, r, res = pcg_fused(A, b, None, mdiv=sig, tol=1e-6, maxit=40, minit=5)
+    f32 = x.dtype == torch.float32
+    # C5 shard: exactly 10 fused iterations; C3: the stopping rule live
+    sol, r, res = pcg_fused(A, b, None, mdiv=sig, tol=1e-6 if f32 else 0.0, maxit=40 if f32 else 10,
+                            minit=5 if f32 else 10)
     r0 = torch.linalg.vector_norm(b.double()).item()
     rk = torch.linalg.vector_norm((A(sol) - b).double()).item()
     assert res.iters >= 5 and rk < 1e-4 * r0
     assert (sol - x).abs().max().item() < 1e-3 * x.abs().max().item()
+
+
+# ------------------------------------------------------- pointwise against the CPU oracle
+@pytest.mark.parametrize('n,dtn,tol', [(4096, 'float32', 1e-5), (8192, 'float64', 1e-12)],
+                         ids=['4096-f32', '8192-f64'])
+def test_band_matvec_pointwise_vs_oracle_at_full_size(n, dtn, tol):
+    """ONE band-matvec of the CPU oracle (oracle/fftconv.psf_convolve_slice = the reference's
+    pad -> r2c -> * psfhat -> c2r -> crop, psf.py:11-29) against plan.apply on the same seeded vector at
+    the headline image size (fp32) and at the C5 size (fp64, nx_psf = 16384), with a COMPLEX psfhat (odd
+    imaginary part: a PSF that is not point-symmetric) and the Tikhonov term through _hessian_psf_slice."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os
+    from oracle import fftconv as ofc
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    rng = np.random.default_rng(420)
+    rdt = np.float32 if dtn == 'float32' else np.float64
+    P = Q = 2 * n
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    amp = np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2)) * (1.0 + 0.5 * rng.random((P, Q // 2 + 1)))
+    ph = 0.3 * np.sin(2 * np.pi * u) + 0.2 * np.sin(2 * np.pi * v)      # odd in (u, v): Hermitian-consistent
+    psfhat = (amp * np.exp(1j * ph)).astype(np.complex64 if rdt == np.float32 else np.complex128)
+    del amp, ph
+    x = rng.standard_normal((n, n)).astype(rdt)
+    sig = rdt(0.37)
+    workers = min(16, os.cpu_count() or 1)
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, rdt)
+    ref = ofc._hessian_psf_slice(xpad, xhat, xout, psfhat, None, Q, x, nthreads=workers, sigmainv=sig)
+    del xpad, xhat
+    plan = PsfConvPlan(torch.from_numpy(psfhat).cuda(), n, n, Q)
+    assert plan.fast_path
+    got = plan.apply(torch.from_numpy(x).cuda(), sigmainv=float(sig)).cpu().numpy()
+    plan.close()
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref).max()
+    assert err < tol, err
 
 
 # ---------------------------------------------------------------- BASELINE config #4

@@ -1,0 +1,84 @@
+"""Per-phase time table of the three persistent convolution kernels from the DIAGNOSTIC build
+(make -C pfb_clean_amd/csrc stamp -> libpfb_hip_stamp.so: thread 0 of every workgroup stamps the 100 MHz
+wall clock at its phase boundaries for loop trips 2..5).  The stamps perturb the schedule a little (each is
+an s_memrealtime + a store); totals are reported next to the un-stamped kernel time for that reason.
+
+    python tools/stamp_report.py [size] [bands] [f32|f64]
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['PFB_HIP_LIB'] = os.path.join(ROOT, 'pfb_clean_amd', 'libpfb_hip_stamp.so')
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+from pfb_clean_amd import _lib, _dev                     # noqa: E402
+from pfb_clean_amd.operators.psf import PsfConvPlan      # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+dt = torch.float64 if (len(sys.argv) > 3 and sys.argv[3] == 'f64') else torch.float32
+cdt = torch.complex128 if dt == torch.float64 else torch.complex64
+ITS, NWG, NSLOT = 4, 1024, 16
+NAMES = {
+    0: ('k_row_fwd_pow2p', ['top -> pack + w_M multiply', 'forward FFT x2 (even, odd bins)',
+                             'LDS write even + issue next x + barriers', 'post-process + store even bins',
+                             'LDS write odd + barriers', 'post-process + store odd bins', 'final barrier']),
+    1: ('k_col_pow2p', ['aw = a w, issue psf_e + next a', 'FFT (even)', 'wait psf_e, multiply', 'issue psf_o, IFFT (even)',
+                        'FFT (odd)', 'wait psf_o, multiply', 'IFFT (odd)', 'combine + stores issued']),
+    2: ('k_row_inv_pow2p', ['barrier (top)', 'wait y_even, scatter to LDS', 'issue y_odd + barrier', 'build (even)',
+                            'IFFT (even)', 'park + barrier', 'wait y_odd, scatter', 'issue x, r, next y_even + barrier',
+                            'build (odd)', 'IFFT (odd)', 'wait x, r; epilogue + stores issued']),
+}
+
+lib = _lib.load()
+raw = C.CDLL(_lib.LIB_PATH)
+raw.pfb_debug_set_stamps.argtypes = [C.c_void_p]
+dev = torch.device('cuda')
+g = torch.Generator(device=dev).manual_seed(1)
+psfhat = (torch.rand((nb, 2 * n, n + 1), generator=g, device=dev, dtype=dt) / nb).to(cdt)
+plan = PsfConvPlan(psfhat, n, n, 2 * n)
+x = torch.randn((nb, n, n), generator=g, device=dev, dtype=dt)
+r = torch.randn((nb, n, n), generator=g, device=dev, dtype=dt)
+out = torch.empty_like(x)
+dots = torch.zeros(3, dtype=torch.float64, device=dev)
+
+
+def apply():
+    _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(x), None, 0.0, 0.1, _dev.ptr(out),
+                                          _dev.ptr(x), _dev.ptr(r), _dev.ptr(dots), _dev.stream()))
+
+
+for _ in range(3):
+    apply()
+buf = torch.zeros(3 * NWG * ITS * NSLOT, dtype=torch.int64, device=dev)
+assert raw.pfb_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
+plan.set_profiling(1)
+apply()
+torch.cuda.synchronize()
+ms, napply = plan.get_profile()
+raw.pfb_debug_set_stamps(None)
+st = buf.cpu().numpy().reshape(3, NWG, ITS, NSLOT).astype(np.float64) * 0.01     # 100 MHz ticks -> us
+print(f"# stamp report: {n}^2 x {nb} bands {dt}; kernel times of the stamped launch (HIP events): "
+      f"row_fwd {ms[0]:.3f} ms, col {ms[1]:.3f} ms, row_inv {ms[2]:.3f} ms")
+for kid, (name, phases) in NAMES.items():
+    a = st[kid]
+    live = (a[:, :, 0] > 0) & (a[:, :, len(phases)] > 0)
+    if not live.any():
+        print(f"\n## {name}: no stamps (kernel not used at this size)")
+        continue
+    print(f"\n## {name}: {int(live.any(axis=1).sum())} workgroups, {int(live.sum())} stamped trips; microseconds per trip")
+    print("| phase | mean | p10 | p90 |")
+    print("|---|---|---|---|")
+    tot = np.zeros(live.sum())
+    for k, ph in enumerate(phases):
+        d = (a[:, :, k + 1] - a[:, :, k])[live]
+        tot += d
+        print(f"| {ph} | {d.mean():.2f} | {np.percentile(d, 10):.2f} | {np.percentile(d, 90):.2f} |")
+    print(f"| **sum of phases** | {tot.mean():.2f} | {np.percentile(tot, 10):.2f} | {np.percentile(tot, 90):.2f} |")
+    # trip to trip (includes whatever sits between the last stamp and the next top)
+    nxt = (a[:, 1:, 0] - a[:, :-1, 0])[live[:, 1:] & live[:, :-1]]
+    if nxt.size:
+        print(f"| trip to trip | {nxt.mean():.2f} | {np.percentile(nxt, 10):.2f} | {np.percentile(nxt, 90):.2f} |")
