@@ -89,9 +89,15 @@ int pfb_psfconv_set_psfhat(pfb_conv_plan* plan, const void* psfhat, void* stream
  * (pfb/operators/gridder.py:712-714 and pfb/utils/fft.py:7-9).  psf: (nband, nx_psf, ny_psf)
  * real, row-major.  psfhat_out: NULL, or (nband, nx_psf, ny_psf/2+1) complex that also
  * receives the transform in the reference's layout (e.g. for the DDS PSFHAT variable).
- * One workgroup transforms one line in LDS, so 2*max(nx_psf, ny_psf/2)*sizeof(complex) must fit
- * 160 KB (nx_psf <= 10240 fp32 / 5120 fp64); PFB_ERR_UNSUPPORTED beyond that. */
+ * Power-of-two plans (nx_psf = 2 nx, ny_psf = 2 ny: every BASELINE size up to 16384 x 16384 fp64) run it on
+ * the fast path's own register-FFT row / column kernels; other plans on the line-in-LDS kernels.  Synchronous. */
 int pfb_psfconv_set_psf(pfb_conv_plan* plan, const void* psf, void* psfhat_out, void* stream);
+
+/* The same transform without a plan, for ANY grid whose lengths are 13-smooth and whose ny_psf is even:
+ * psfhat (nband, nx_psf, ny_psf/2+1) = r2c(ifftshift(psf)).  Lines that fit the LDS take the
+ * one-workgroup-per-line kernels, longer ones (nx_psf > 10240 fp32 / 5120 fp64) multi-launch Stockham passes
+ * in global memory -- no length limit.  Plan time (gridder.py:712-714 runs once per gridding run).  Synchronous. */
+int pfb_psfhat_from_psf(int dtype, const void* psf, int nband, int nx_psf, int ny_psf, void* psfhat, void* stream);
 
 /* Re-grid a PSF transform: psfhat on the (nx_psf, ny_psf) grid -> psfhat2 of the SAME image-space
  * PSF on an (nx_psf2, ny_psf2) grid (both (nband, n, m/2+1) complex, row-major), for images of
@@ -100,8 +106,8 @@ int pfb_psfconv_set_psf(pfb_conv_plan* plan, const void* psf, void* psfhat_out, 
  * nx_psf < 2 nx is reproduced), which needs nx_psf2 >= 2 nx - 1, ny_psf2 >= 2 ny - 1.
  * The convolution psf.py:11-56 on the old grid and on the new grid (image zero-padded to
  * nx_psf2/2 x ny_psf2/2, result cropped) then agree to rounding; the host layer uses this to run
- * arbitrary image sizes on the power-of-two fast path.  Plan-time, synchronous.  Lines must
- * fit the LDS (<= 10240 complex64 / 5120 complex128), lengths 13-smooth, last axes even. */
+ * arbitrary image sizes on the power-of-two fast path.  Plan-time, synchronous.  Lengths 13-smooth, last axes
+ * even; lines of any length (beyond the LDS: multi-launch global-memory passes). */
 int pfb_psfhat_regrid(int dtype, const void* psfhat, int nband, int nx, int ny, int nx_psf, int ny_psf,
                       int nx_psf2, int ny_psf2, void* psfhat2, void* stream);
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     'pfb_psfconv_apply': (_i, [_vp, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp]),
     'pfb_psfconv_set_psf': (_i, [_vp, _vp, _vp, _vp]),
     'pfb_psfhat_regrid': (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'pfb_psfhat_from_psf': (_i, [_i, _vp, _i, _i, _i, _vp, _vp]),
     'pfb_psfconv_apply_dots': (_i, [_vp, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp]),
     'pfb_psfconv_plan_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz)]),
     'pfb_psfconv_set_profiling': (_i, [_vp, _i]),

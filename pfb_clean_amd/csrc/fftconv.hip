@@ -13,6 +13,7 @@
 // mixed-radix Stockham FFT in LDS; fftconv_pow2.hip supplies the fast versions of the
 // same three stages on the same layouts.
 #include "conv_plan.hpp"
+#include "fft_long.hpp"
 #include <vector>
 #include <cstring>
 #include <cstdlib>
@@ -338,15 +339,48 @@ static int set_lds_limits(const pfb_conv_plan*) {
     return PFB_OK;
 }
 
+// a line of n complex values fits the LDS ping-pong buffers of the one-workgroup-per-line kernels
+template <typename T> static inline bool line_fits_lds(int n) { return 2 * sizeof(cplx<T>) * (size_t)n <= (size_t)160 * 1024; }
+
+// psfhat_out (nband, P, M+1) = r2c(ifftshift(psf)) for ANY 13-smooth grid: rows, then columns in place; a line that
+// fits the LDS takes the one-workgroup-per-line kernels, a longer one the global-memory passes (fft_long.hpp).
+// twP / twQ: exp(-2 pi i n / P), exp(-2 pi i n / Q).  Synchronous.
 template <typename T>
-static int psfhat_from_psf_t(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStream_t st) {
-    const size_t lds_r = 2 * sizeof(cplx<T>) * (size_t)p->M, lds_c = 2 * sizeof(cplx<T>) * (size_t)p->P;
-    hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(p->P, p->nband), dim3(256), lds_r, st, (const T*)psf,
-                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twQ, p->P, p->Q, p->frow, 1);
-    hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(p->M + 1, p->nband), dim3(256), lds_c, st,
-                       (cplx<T>*)psfhat_out, (const cplx<T>*)p->twP, p->P, p->M + 1, p->fcol);
+static int psfhat_from_psf_t(const void* psf, void* psfhat_out, int nband, int P, int Q, const FftFactors& frow,
+                             const FftFactors& fcol, const void* twP, const void* twQ, hipStream_t st) {
+    const int M = Q / 2;
+    const size_t lds_r = 2 * sizeof(cplx<T>) * (size_t)M, lds_c = 2 * sizeof(cplx<T>) * (size_t)P;
+    if (line_fits_lds<T>(M))
+        hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(P, nband), dim3(256), lds_r, st, (const T*)psf,
+                           (cplx<T>*)psfhat_out, (const cplx<T>*)twQ, P, Q, frow, 1);
+    else if (int rc = long_rows_r2c<T>((const T*)psf, (cplx<T>*)psfhat_out, (const cplx<T>*)twQ, nband, P, Q, frow, 1, st);
+             rc != PFB_OK)
+        return rc;
+    if (line_fits_lds<T>(P))
+        hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(M + 1, nband), dim3(256), lds_c, st,
+                           (cplx<T>*)psfhat_out, (const cplx<T>*)twP, P, M + 1, fcol);
+    else if (int rc = long_cols<T, false>((cplx<T>*)psfhat_out, (const cplx<T>*)twP, nband, P, M + 1, fcol, st);
+             rc != PFB_OK)
+        return rc;
     PFB_HIP_CHECK(hipGetLastError());
+    PFB_HIP_CHECK(hipStreamSynchronize(st));
     return PFB_OK;
+}
+
+// plan-less form (pfb_psfhat_from_psf): builds its own factor lists and twiddle tables
+template <typename T>
+static int psfhat_from_psf_grid(const void* psf, void* psfhat_out, int nband, int P, int Q, hipStream_t st) {
+    FftFactors fr, fc;
+    PFB_REQUIRE(plan_factors(Q / 2, &fr) && plan_factors(P, &fc), PFB_ERR_UNSUPPORTED,
+                "psfhat_from_psf: (%d,%d) has a prime factor > 13", P, Q);
+    void *twP = nullptr, *twQ = nullptr;
+    int rc = upload_twiddles<T>(P, &twP);
+    if (rc == PFB_OK) rc = upload_twiddles<T>(Q, &twQ);
+    if (rc == PFB_OK) rc = set_lds_limits<T>(nullptr);
+    if (rc == PFB_OK) rc = psfhat_from_psf_t<T>(psf, psfhat_out, nband, P, Q, fr, fc, twP, twQ, st);
+    if (twP) (void)hipFree(twP);
+    if (twQ) (void)hipFree(twQ);
+    return rc;
 }
 
 // psfhat on the (P, Q) grid -> psfhat of the SAME image-space PSF on a (P2, Q2) grid, for images
@@ -373,18 +407,37 @@ static int psfhat_regrid_t(const void* psfhat, int nband, int nx, int ny, int P,
     }
     if (rc == PFB_OK) {
         set_lds_limits<T>(nullptr);
+        // every transform picks the one-workgroup-per-line LDS kernel when its line fits, else the global-memory passes
         (void)hipMemcpyAsync(spec, psfhat, nspec * sizeof(cplx<T>), hipMemcpyDeviceToDevice, st);
-        hipLaunchKernelGGL((k_psfhat_cols<T, true>), dim3(M + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P, st,
-                           (cplx<T>*)spec, (const cplx<T>*)twP, P, M + 1, fc);
-        hipLaunchKernelGGL((k_psf_rows_c2r<T>), dim3(P, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M, st,
-                           (const cplx<T>*)spec, (T*)psf, (const cplx<T>*)twQ, P, Q, fr);
-        hipLaunchKernelGGL((k_psf_embed<T>), dim3((Q2 + 255) / 256, P2, nband), dim3(256), 0, st, (const T*)psf,
-                           (T*)psf2, nx, ny, P, Q, P2, Q2, (T)(1.0 / ((double)P * (double)Q)));
-        hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(P2, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M2, st,
-                           (const T*)psf2, (cplx<T>*)psfhat2, (const cplx<T>*)twQ2, P2, Q2, fr2, 0);
-        hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(M2 + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P2,
-                           st, (cplx<T>*)psfhat2, (const cplx<T>*)twP2, P2, M2 + 1, fc2);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        if (line_fits_lds<T>(P))
+            hipLaunchKernelGGL((k_psfhat_cols<T, true>), dim3(M + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P, st,
+                               (cplx<T>*)spec, (const cplx<T>*)twP, P, M + 1, fc);
+        else
+            rc = long_cols<T, true>((cplx<T>*)spec, (const cplx<T>*)twP, nband, P, M + 1, fc, st);
+        if (rc == PFB_OK) {
+            if (line_fits_lds<T>(M))
+                hipLaunchKernelGGL((k_psf_rows_c2r<T>), dim3(P, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M, st,
+                                   (const cplx<T>*)spec, (T*)psf, (const cplx<T>*)twQ, P, Q, fr);
+            else
+                rc = long_rows_c2r<T>((const cplx<T>*)spec, (T*)psf, (const cplx<T>*)twQ, nband, P, Q, fr, st);
+        }
+        if (rc == PFB_OK) {
+            hipLaunchKernelGGL((k_psf_embed<T>), dim3((Q2 + 255) / 256, P2, nband), dim3(256), 0, st, (const T*)psf,
+                               (T*)psf2, nx, ny, P, Q, P2, Q2, (T)(1.0 / ((double)P * (double)Q)));
+            if (line_fits_lds<T>(M2))
+                hipLaunchKernelGGL((k_psfhat_rows<T>), dim3(P2, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)M2, st,
+                                   (const T*)psf2, (cplx<T>*)psfhat2, (const cplx<T>*)twQ2, P2, Q2, fr2, 0);
+            else
+                rc = long_rows_r2c<T>((const T*)psf2, (cplx<T>*)psfhat2, (const cplx<T>*)twQ2, nband, P2, Q2, fr2, 0, st);
+        }
+        if (rc == PFB_OK) {
+            if (line_fits_lds<T>(P2))
+                hipLaunchKernelGGL((k_psfhat_cols<T, false>), dim3(M2 + 1, nband), dim3(256), 2 * sizeof(cplx<T>) * (size_t)P2,
+                                   st, (cplx<T>*)psfhat2, (const cplx<T>*)twP2, P2, M2 + 1, fc2);
+            else
+                rc = long_cols<T, false>((cplx<T>*)psfhat2, (const cplx<T>*)twP2, nband, P2, M2 + 1, fc2, st);
+        }
+        if (rc == PFB_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
             set_error("psfhat_regrid: kernel launch failed");
             rc = PFB_ERR_HIP;
         }
@@ -556,10 +609,6 @@ int pfb_psfconv_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, voi
         return rc;
     }
     const size_t csz = p->dtype == PFB_F32 ? 8 : 16;
-    const size_t lds_need = 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
-    PFB_REQUIRE(lds_need <= 160 * 1024, PFB_ERR_UNSUPPORTED,
-                "set_psf: a (%d,%d) PSF grid needs %zu B of LDS per line (> 160 KB); hand over psfhat instead",
-                p->P, p->Q, lds_need);
     hipStream_t st = as_stream(stream);
     void* tmp = nullptr;
     void* dst = psfhat_out;
@@ -567,14 +616,23 @@ int pfb_psfconv_set_psf(pfb_conv_plan* p, const void* psf, void* psfhat_out, voi
         PFB_HIP_CHECK(hipMalloc(&tmp, csz * (size_t)p->nband * p->P * (p->M + 1)));
         dst = tmp;
     }
-    int rc = p->dtype == PFB_F32 ? psfhat_from_psf_t<float>(p, psf, dst, st)
-                                 : psfhat_from_psf_t<double>(p, psf, dst, st);
+    int rc = p->dtype == PFB_F32
+        ? psfhat_from_psf_t<float>(psf, dst, p->nband, p->P, p->Q, p->frow, p->fcol, p->twP, p->twQ, st)
+        : psfhat_from_psf_t<double>(psf, dst, p->nband, p->P, p->Q, p->frow, p->fcol, p->twP, p->twQ, st);
     if (rc == PFB_OK) rc = pfb_psfconv_set_psfhat(p, dst, stream);
     if (tmp) {
         (void)hipStreamSynchronize(st);
         (void)hipFree(tmp);
     }
     return rc;
+}
+
+int pfb_psfhat_from_psf(int dtype, const void* psf, int nband, int nx_psf, int ny_psf, void* psfhat, void* stream) {
+    PFB_REQUIRE(psf && psfhat && nband > 0 && nx_psf > 0 && ny_psf > 0, PFB_ERR_INVALID, "psfhat_from_psf: bad argument");
+    PFB_REQUIRE(dtype == PFB_F32 || dtype == PFB_F64, PFB_ERR_INVALID, "psfhat_from_psf: bad dtype");
+    PFB_REQUIRE(ny_psf % 2 == 0, PFB_ERR_UNSUPPORTED, "psfhat_from_psf: ny_psf=%d must be even", ny_psf);
+    return dtype == PFB_F32 ? psfhat_from_psf_grid<float>(psf, psfhat, nband, nx_psf, ny_psf, as_stream(stream))
+                            : psfhat_from_psf_grid<double>(psf, psfhat, nband, nx_psf, ny_psf, as_stream(stream));
 }
 
 int pfb_psfhat_regrid(int dtype, const void* psfhat, int nband, int nx, int ny, int nx_psf, int ny_psf,
@@ -584,12 +642,6 @@ int pfb_psfhat_regrid(int dtype, const void* psfhat, int nband, int nx, int ny, 
     PFB_REQUIRE(ny_psf % 2 == 0 && ny_psf2 % 2 == 0, PFB_ERR_UNSUPPORTED, "psfhat_regrid: odd last axis");
     PFB_REQUIRE(nx_psf2 >= 2 * nx - 1 && ny_psf2 >= 2 * ny - 1, PFB_ERR_INVALID,
                 "psfhat_regrid: the new grid (%d,%d) must hold every offset of a (%d,%d) image", nx_psf2, ny_psf2, nx, ny);
-    const size_t csz = dtype == PFB_F32 ? 8 : 16;
-    int big = nx_psf > nx_psf2 ? nx_psf : nx_psf2;
-    if (ny_psf / 2 > big) big = ny_psf / 2;
-    if (ny_psf2 / 2 > big) big = ny_psf2 / 2;
-    PFB_REQUIRE(2 * csz * (size_t)big <= 160 * 1024, PFB_ERR_UNSUPPORTED,
-                "psfhat_regrid: a line of %d complex values does not fit the LDS", big);
     return dtype == PFB_F32
         ? psfhat_regrid_t<float>(psfhat, nband, nx, ny, nx_psf, ny_psf, nx_psf2, ny_psf2, psfhat2, as_stream(stream))
         : psfhat_regrid_t<double>(psfhat, nband, nx, ny, nx_psf, ny_psf, nx_psf2, ny_psf2, psfhat2, as_stream(stream));

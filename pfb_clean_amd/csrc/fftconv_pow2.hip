@@ -118,7 +118,7 @@ constexpr int row_groups() {
     constexpr int TPB = L / E;
     int G = 256 / TPB > GMAX ? 256 / TPB : GMAX;
     const int stride = RegFft<T, L, E>::LDS_ELEMS + 4;
-    while (G > 2 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 384 > LDS_BUDGET)) G /= 2;
+    while (G > 1 && (G * TPB > 1024 || (size_t)G * stride * sizeof(cplx<T>) + 384 > LDS_BUDGET)) G /= 2;
     return G;
 }
 template <int H, int E>

@@ -3,18 +3,27 @@ PSFHAT production -- pfb/operators/gridder.py:712-714 with pfb/operators/fft.py:
 
     psfhat = r2c(ifftshift(psf), axes=(0, 1), inorm=0)
 
-This runs ONCE per gridding run (plan time), not inside the PCG / PD loops.  It is produced by
-the library's own line-FFT kernels (pfb_psfconv_set_psf: one workgroup per PSF row / column,
-mixed-radix Stockham in LDS) whenever a PSF line fits the LDS (nx_psf <= 10240 fp32 / 5120
-fp64, lengths 13-smooth, ny_psf even); larger or odd grids go through torch.fft on the device
-tensor (rocFFT) so that a worker still stays device resident.  `PsfConvPlan.from_psf` builds
-the convolution plan from the PSF without the transform ever leaving the library.
+This runs ONCE per gridding run (plan time), not inside the PCG / PD loops.  It is produced by the library's own
+kernels for every grid whose lengths are 13-smooth with an even ny_psf (what pfb's grid worker makes, grid.py:276-285):
+
+  * power-of-two grids in the fast path's range (nx_psf <= 16384, ny_psf <= 32768 fp32 / 16384 fp64: every BASELINE
+    size) on the register-FFT row / column kernels of the convolution itself (pfb_psfconv_set_psf on a fast plan);
+  * any other grid through pfb_psfhat_from_psf: one workgroup per line in LDS while a line fits, multi-launch
+    Stockham passes in global memory beyond that -- no length limit.
+
+Only an ODD ny_psf (which the reference never produces) falls back to torch.fft on the device tensor.
+`PsfConvPlan.from_psf` builds the convolution plan from the PSF without the transform ever leaving the library.
 """
+import ctypes as C
+
 import torch
 
 from .. import _dev, _lib
-from .._lib import PfbHipError
-from .psf import PsfConvPlan
+from .psf import PsfConvPlan, NX_FAST_MAX, NY_FAST_MAX
+
+
+def _is_pow2(n):
+    return n > 0 and (n & (n - 1)) == 0
 
 
 def psfhat_from_psf(psf):
@@ -22,18 +31,23 @@ def psfhat_from_psf(psf):
     Returns complex psfhat (..., nx_psf, ny_psf//2 + 1), numpy in -> numpy out."""
     p = _dev.to_dev(psf)
     squeeze = p.ndim == 2
-    out = None
-    if p.shape[-1] % 2 == 0 and p.dtype in (torch.float32, torch.float64):
-        try:
-            # a throw-away plan for a 1 x 2 image: only its tables and the PSF kernels are used
-            plan, out = PsfConvPlan.from_psf(p, 1, 2, want_psfhat=True)
+    if squeeze:
+        p = p[None]
+    if p.ndim != 3:
+        raise ValueError("psf must be (nx_psf, ny_psf) or (nband, nx_psf, ny_psf)")
+    nband, P, Q = (int(v) for v in p.shape)
+    if Q % 2 == 0 and p.dtype in (torch.float32, torch.float64):
+        p = p.contiguous()
+        if (_is_pow2(P) and _is_pow2(Q) and 128 <= P <= 2 * NX_FAST_MAX and 256 <= Q <= 2 * NY_FAST_MAX[p.dtype]):
+            # a fast plan for the (P/2, Q/2) image this grid oversamples by 2: its row / column kernels do the work
+            plan, out = PsfConvPlan.from_psf(p, P // 2, Q // 2, want_psfhat=True)
             plan.close()
-        except PfbHipError as e:
-            if e.code != _lib.PFB_ERR_UNSUPPORTED:
-                raise
-            out = None
-    if out is None:
-        out = torch.fft.rfft2(torch.fft.ifftshift(p, dim=(-2, -1)), dim=(-2, -1))
-    elif squeeze:
+        else:
+            lib = _lib.load()
+            out = torch.empty((nband, P, Q // 2 + 1), dtype=_dev.CPLX_OF[p.dtype], device=p.device)
+            _lib.check(lib.pfb_psfhat_from_psf(_dev.code(p.dtype), _dev.ptr(p), nband, P, Q, _dev.ptr(out), _dev.stream()))
+    else:
+        out = torch.fft.rfft2(torch.fft.ifftshift(p, dim=(-2, -1)), dim=(-2, -1))      # odd ny_psf only
+    if squeeze:
         out = out[0]
     return out.cpu().numpy() if _dev.is_numpy(psf) else out

@@ -32,10 +32,19 @@ def _pow2ceil(n):
     return p
 
 
+# what the kernels take (csrc): the fast path serves power-of-two images 64 <= nx <= 8192, 128 <= ny <= NY_FAST_MAX
+# with nx_psf = 2 nx, ny_psf = 2 ny; the coverage ("generic") kernels hold one line in two LDS buffers
+NX_FAST_MAX = 8192
+NY_FAST_MAX = {torch.float32: 16384, torch.float64: 8192}
+LINE_MAX = {torch.float32: 10240, torch.float64: 5120}
+
+
 def _embed_grid(nx, ny, nx_psf, ny_psf, rdtype):
-    """(nx2, ny2) of the power-of-two plan an (nx, ny | nx_psf, ny_psf) problem is embedded in,
-    or None: already a fast-path size, switched off (PFB_NO_EMBED / PFB_FORCE_GENERIC), more than
-    3x the pixels, or beyond what pfb_psfhat_regrid and the fast kernels take."""
+    """(nx2, ny2) of the power-of-two plan an (nx, ny | nx_psf, ny_psf) problem is embedded in, or None: already
+    a fast-path size, switched off (PFB_NO_EMBED / PFB_FORCE_GENERIC), odd ny_psf, or beyond the fast kernels.
+    Problems the coverage kernels can run (every line fits the LDS) are only embedded when the padded problem has
+    at most 3x the pixels; problems they cannot run (nx_psf > 10240 fp32 / 5120 fp64: 6000^2, 7200^2 ... images
+    with psf-oversize 2) are embedded whenever the fast path can hold them."""
     import os
     if os.environ.get('PFB_NO_EMBED', '0') not in ('', '0') or os.environ.get('PFB_FORCE_GENERIC', '0') not in ('', '0'):
         return None
@@ -44,10 +53,10 @@ def _embed_grid(nx, ny, nx_psf, ny_psf, rdtype):
     nx2, ny2 = max(64, _pow2ceil(nx)), max(128, _pow2ceil(ny))
     if (nx2, ny2) == (nx, ny) and (nx_psf, ny_psf) == (2 * nx, 2 * ny):
         return None
-    line_max = 10240 if rdtype == torch.float32 else 5120
-    if max(2 * nx2, ny2, nx_psf, ny_psf // 2) > line_max:
+    if nx2 > NX_FAST_MAX or ny2 > NY_FAST_MAX[rdtype]:
         return None
-    if nx2 * ny2 > 3 * nx * ny:
+    generic_ok = max(nx_psf, ny_psf // 2) <= LINE_MAX[rdtype]
+    if generic_ok and nx2 * ny2 > 3 * nx * ny:
         return None
     return nx2, ny2
 
@@ -107,11 +116,20 @@ class PsfConvPlan:
 
     def _regrid(self, ph, grid2):
         """psfhat on the caller's grid -> psfhat on the (2 nx2, 2 ny2) grid, or None when the
-        library cannot do it (line too long for the LDS, prime factor > 13).  Done in fp64
-        whenever those lines fit, so that fp32 plans see no extra rounding from the detour."""
+        library cannot do it (prime factor > 13).  Done in fp64 (memory permitting: the detour holds
+        the spectrum, the PSF and the embedded PSF of all bands at once), so that fp32 plans see no extra
+        rounding from it."""
         nx2, ny2 = grid2
         cdt = ph.dtype
-        for work in ((torch.complex128, 1), (cdt, self.code)):
+        # fp64 working set of pfb_psfhat_regrid: spec + psf + psf2 + psfhat2 (+ transform scratch)
+        need64 = 16 * self.nband * (self.nx_psf * self.nyo2 * 2 + 2 * nx2 * (ny2 + 1) * 2) + 8 * self.nband * (
+            self.nx_psf * self.lastsize + 4 * nx2 * ny2) * 2
+        try:
+            free = torch.cuda.mem_get_info(ph.device)[0]
+        except Exception:
+            free = 0
+        works = ((torch.complex128, 1), (cdt, self.code)) if need64 < 0.6 * free else ((cdt, self.code),)
+        for work in works:
             src = ph.to(work[0]) if ph.dtype != work[0] else ph
             dst = torch.empty((self.nband, 2 * nx2, ny2 + 1), dtype=work[0], device=ph.device)
             rc = self._lib.pfb_psfhat_regrid(work[1], _dev.ptr(src), self.nband, self.nx, self.ny,
@@ -140,8 +158,7 @@ class PsfConvPlan:
         """Build the plan straight from the real PSF cube (nband, nx_psf, ny_psf) | (nx_psf, ny_psf):
         psfhat = r2c(ifftshift(psf)) is produced by the library's own kernels
         (pfb_psfconv_set_psf; gridder.py:712-714) and never leaves the device.  With
-        want_psfhat=True also returns it in the reference's layout.  Raises PfbHipError
-        (unsupported) when a PSF line does not fit the LDS (nx_psf > 10240 fp32 / 5120 fp64)."""
+        want_psfhat=True also returns it in the reference's layout."""
         lib = _lib.load()
         p = _dev.to_dev(psf)
         if p.ndim == 2:

@@ -88,7 +88,11 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
     (64, 128, 128, 256), (128, 256, 256, 512), (512, 128, 1024, 256), (1024, 1024, 2048, 2048),
     (2048, 256, 4096, 512), (256, 4096, 512, 8192), (4096, 128, 8192, 256),
     # the largest instantiations (BASELINE config #5 is 8192 x 8192)
-    (8192, 128, 16384, 256), (64, 8192, 128, 16384), (128, 2048, 256, 4096),
+    (8192, 128, 16384, 256), (64, 8192, 128, 16384), (128, 2048, 256, 4096), (64, 16384, 128, 32768),
+    # PSF lines beyond the LDS (nx_psf > 10240 fp32 / 5120 fp64; grid.py:276-285 good_size grids of 6000^2, 7200^2 ...
+    # images): embedded in the power-of-two fast path, the re-gridding runs its long lines as global-memory passes
+    (6000, 96, 12000, 192), (7200, 64, 14400, 128), (5040, 64, 10080, 128), (3000, 64, 6000, 128),
+    (8000, 64, 16000, 128), (6000, 96, 9000, 144), (96, 7200, 192, 14400),
 ]
 
 

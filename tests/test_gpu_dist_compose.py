@@ -309,7 +309,11 @@ def test_cg_dct_nested_dict(kind):
 
 
 @pytest.mark.parametrize('rdt', [np.float64, np.float32])
-@pytest.mark.parametrize('shape', [(2, 128, 128), (1, 96, 80), (2, 60, 100), (1, 45, 66), (1, 512, 2048)])
+@pytest.mark.parametrize('shape', [(2, 128, 128), (1, 96, 80), (2, 60, 100), (1, 45, 66), (1, 512, 2048),
+                                   # power-of-two: the fast path's row / column kernels (largest column / row lines)
+                                   (2, 2048, 1024), (1, 16384, 256), (1, 128, 16384),
+                                   # lines beyond the LDS, not powers of two: global-memory Stockham passes
+                                   (1, 12000, 96), (1, 96, 28800), (1, 14400, 128)])
 def test_native_psfhat_producer(shape, rdt):
     """pfb_psfconv_set_psf (gridder.py:712-714: r2c(ifftshift(psf))) against the oracle, pow2 and
     mixed-radix grids, odd nx_psf; and a plan built straight from the PSF convolves like one built
