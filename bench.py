@@ -294,6 +294,10 @@ def bench_pcg(ctx):
     }
     if cpu:
         out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+    if ctx['use_pg'] and getattr(res, 'hook_calls', 0):
+        out["allreduce_hook"] = {"backend": os.environ.get('PFB_DIST_BACKEND', 'nccl'), "calls_per_solve": res.hook_calls,
+                                 "host_us_per_call": round(1e6 * res.hook_host_s / res.hook_calls, 2),
+                                 "what": "ctypes callback -> torch.distributed.all_reduce of 4-7 fp64 scalars on the solver's stream"}
     return out
 
 

@@ -17,6 +17,7 @@
 // powers with <= 3 chained complex multiplies (error <= ~5 ulp, measured 2.4).
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 namespace pfb {
 
@@ -206,6 +207,18 @@ template <typename T, bool INV> struct Dft<T, INV, 16> {
 // early-issued load (prefetch of the next operand) to complete first.
 // SEQX: the NV transforms of runN share ONE LDS buffer and exchange one after the other
 // (twice the barriers per pass, NV times less LDS).
+// Pass hook.  A persistent kernel that wants memory traffic in flight WHILE a transform runs hands runN / run a
+// callable that is invoked once at the top of every pass with std::integral_constant<int, pass index>: it issues a
+// compile-time slice of the kernel's prefetch loads there.  Why: a wave that issues more vector-memory instructions
+// than the CU's memory pipeline has room for simply STALLS AT ISSUE until older requests have returned
+// (profiles/r02_a_phase_stamps: "issue x, r, next y + barrier" = 7.6 us of a 22.6 us row-inverse trip, with every
+// wave of the one resident workgroup stalled together and nothing computing).  A few loads per pass keep the
+// pipeline full without parking all the waves at once.
+struct NoPassHook {
+    template <typename K> __device__ __forceinline__ void operator()(K) const {}
+};
+template <int K> using PassIdx = std::integral_constant<int, K>;
+
 template <typename T, int N, int E, bool WAVE = false, int DBOFF = 0, bool SQTW = false, bool SEQX = false>
 struct RegFft {
     static_assert((N & (N - 1)) == 0 && (E & (E - 1)) == 0 && N >= E, "power-of-two sizes");
@@ -311,11 +324,12 @@ struct RegFft {
     // NV independent transforms advance together: same barriers, NV LDS buffers
     // (lds + n * LDS_ELEMS), NV * E values in registers.  NV = 1 for the row kernels,
     // NV = 2 for the column kernel (two frequency columns per 16-byte access).
-    template <bool INV, int P, int NV, int XCH = 0>
+    template <bool INV, int P, int NV, int XCH = 0, int K = 0, typename Hook = NoPassHook>
     __device__ __forceinline__ static void pass(cplx<T> (&v)[NV][E], cplx<T>* lds_in, int t,
-                                                const cplx<T>* __restrict__ ptw) {
+                                                const cplx<T>* __restrict__ ptw, const Hook& hook = Hook()) {
         constexpr int R = PassRadix<N, E, P>::R;
         constexpr int NB = E / R;
+        hook(PassIdx<K>{});
 #pragma unroll
         for (int n = 0; n < NV; ++n) butterflies<INV, P>(v[n], t, ptw);
         if constexpr (P * R < N) {
@@ -358,7 +372,7 @@ struct RegFft {
                 for (int j = 0; j < E; ++j) v[n][j] = rp[n * LDS_ELEMS + cxpad<P, R>(TPB * j)];
             }
             }
-            pass<INV, P * R, NV, XCH + 1>(v, lds_in, t, ptw);
+            pass<INV, P * R, NV, XCH + 1, K + 1, Hook>(v, lds_in, t, ptw, hook);
         }
     }
 
@@ -367,20 +381,21 @@ struct RegFft {
     // X0: parity of the first exchange (DBOFF > 0 only).  A transform with an ODD number of exchanges
     // ends on the buffer it started on, so back-to-back transforms without a barrier in between must
     // alternate X0 (0, 1, 0, ...) to keep "the buffer being written was last read two barriers ago".
-    template <bool INV, int NV, int X0 = 0>
+    template <bool INV, int NV, int X0 = 0, typename Hook = NoPassHook>
     __device__ __forceinline__ static void runN(cplx<T> (&v)[NV][E], cplx<T>* lds, int t,
-                                                const cplx<T>* __restrict__ ptw) {
-        pass<INV, 1, NV, X0>(v, lds, t, ptw);
+                                                const cplx<T>* __restrict__ ptw, const Hook& hook = Hook()) {
+        pass<INV, 1, NV, X0, 0, Hook>(v, lds, t, ptw, hook);
     }
     template <int P = 1> static constexpr int nxch() {       // LDS exchanges per transform
         constexpr int R = PassRadix<N, E, P>::R;
         if constexpr (P * R < N) return 1 + nxch<P * R>();
         else return 0;
     }
-    template <bool INV>
+    static constexpr int NPASS = nxch<1>() + 1;               // passes per transform (= hook calls)
+    template <bool INV, typename Hook = NoPassHook>
     __device__ __forceinline__ static void run(cplx<T> (&v)[E], cplx<T>* lds, int t,
-                                               const cplx<T>* __restrict__ ptw) {
-        pass<INV, 1, 1>(reinterpret_cast<cplx<T>(&)[1][E]>(v), lds, t, ptw);
+                                               const cplx<T>* __restrict__ ptw, const Hook& hook = Hook()) {
+        pass<INV, 1, 1, 0, 0, Hook>(reinterpret_cast<cplx<T>(&)[1][E]>(v), lds, t, ptw, hook);
     }
 };
 

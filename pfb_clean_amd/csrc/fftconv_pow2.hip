@@ -144,6 +144,22 @@ __device__ __forceinline__ P* opaque(P* p) {
     return p;
 }
 
+// XCD-aware row-group order of the plain row kernels.  A workgroup of G rows touches T in G x 16-byte pieces; 8 rows
+// make a 128-byte line.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so the
+// SH = 8 / G row groups of one line are given to blocks b, b + 8, .. b + 8 (SH - 1): their pieces meet in ONE L2 and
+// leave it (or are fetched into it) as a full line (speed only: any bijection is correct).
+template <int G>
+__device__ __forceinline__ int xcd_row_group(int bx, int nbx) {
+    constexpr int SH = 8 / G;
+    if constexpr (SH > 1) {
+        if (nbx % (8 * SH) == 0) {
+            const int q = bx / (8 * SH), rem = bx % (8 * SH);
+            return SH * (q * 8 + (rem & 7)) + (rem >> 3);
+        }
+    }
+    return bx;
+}
+
 struct FastDims {
     int nx, ny, M;              // M = ny (packed length), nv = M + 1 columns
     size_t T_band, psf_band;
@@ -300,7 +316,14 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 // so that in steady state no load latency is exposed; the column twiddles w_P^n are
 // loaded once per kernel and stay in registers.
 // DB: a second set of exchange buffers (when the LDS holds it) -- one barrier per exchange instead of two.
-template <typename T, int H, int E, bool DB = false>
+// SPR: the loads are not issued in two bursts (top of the trip / after the first FFT) but a few per FFT PASS
+// (RegFft pass hook): a burst of 16 x 16-byte loads per thread blocks every wave of the workgroup at issue for ~3.8 us
+// of a 16 us trip (profiles/r02_a_phase_stamps_*), with nothing computing meanwhile.  Per trip:
+//     FFT (even)   <- first half of the NEXT item's a          multiply by psf_e (requested during the last IFFT)
+//     IFFT (even)  <- psf_o of this item
+//     FFT (odd)    <- second half of the next item's a         multiply by psf_o
+//     IFFT (odd)   <- psf_e of the NEXT item
+template <typename T, int H, int E, bool DB = false, bool SPR = false>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), 2)
 k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
@@ -311,6 +334,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     constexpr int X1 = (DB && (F::template nxch<1>() & 1)) ? 1 : 0;   // start parity of every other transform
     constexpr int TPB = F::TPB;
     constexpr int GC = col_groups<H, E>();
+    constexpr int NP = F::NPASS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
@@ -334,6 +358,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 
     int item = blockIdx.x * GC + g;
     Blk<T, NVB> an[E];
+    Blk<T, NVB> q[E];
     {
         const bool act = item < nitems;
         const cplx<T>* c0 = col_of(act ? item : 0);
@@ -345,6 +370,11 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 for (int c = 0; c < NVB; ++c) an[j].c[c] = cplx<T>(0, 0);
             }
         }
+        if constexpr (SPR) {
+            const cplx<T>* pe0 = psf_of(act ? item : 0);
+#pragma unroll
+            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe0 + NVB * TPB * j);
+        }
     }
     __syncthreads();                                            // twiddle table visible
 #pragma unroll 1
@@ -354,20 +384,21 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         cplx<T>* col = col_of(active ? item : 0);
         const cplx<T>* pe = psf_of(active ? item : 0);
         const cplx<T>* po = pe + (size_t)H * NVB;
+        // next item (clamped: a trip past the end re-reads a valid block and drops it)
+        const int nxt = item + stride;
+        const bool nact = nxt < nitems;
+        const cplx<T>* cn = col_of(nact ? nxt : (active ? item : 0));
+        const cplx<T>* pen = psf_of(nact ? nxt : (active ? item : 0));
         cplx<T> vv[NVB][E], aw[NVB][E];
-        Blk<T, NVB> q[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
 #pragma unroll
             for (int c = 0; c < NVB; ++c) { vv[c][j] = an[j].c[c]; aw[c][j] = vv[c][j] * tw[j]; }
         }
-        // in issue order (vmcnt retires in order): psf_e of this item, then a of the next
+        if constexpr (!SPR) {
+            // in issue order (vmcnt retires in order): psf_e of this item, then a of the next
 #pragma unroll
-        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
-        {
-            const int nxt = item + stride;
-            const bool nact = nxt < nitems;
-            const cplx<T>* cn = col_of(nact ? nxt : 0);
+            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (nact) an[j] = loadb<T, NVB>(cn + NVB * TPB * j);
@@ -377,9 +408,18 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 }
             }
         }
+        // loads [lo, hi) of a group of CNT, slice k of NP
+        auto ld_an = [&](auto k, int base) {
+            constexpr int K = decltype(k)::value;
+            constexpr int CNT = E / 2;
+#pragma unroll
+            for (int j = (K * CNT) / NP; j < ((K + 1) * CNT) / NP; ++j)
+                an[base + j] = loadb<T, NVB>(cn + NVB * TPB * (base + j));
+        };
         STAMP(1, it, 1);
         // ---- even bins
-        F::template runN<false, NVB, 0>(vv, lds, t, ltw);
+        if constexpr (SPR) F::template runN<false, NVB, 0>(vv, lds, t, ltw, [&](auto k) { ld_an(k, 0); });
+        else F::template runN<false, NVB, 0>(vv, lds, t, ltw);
         STAMP(1, it, 2);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -387,9 +427,17 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
         STAMP(1, it, 3);
+        if constexpr (SPR) {
+            F::template runN<true, NVB, X1>(vv, lds, t, ltw, [&](auto k) {
+                constexpr int K = decltype(k)::value;
 #pragma unroll
-        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
-        F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+            });
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+            F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+        }
         STAMP(1, it, 4);
         cplx<T> ev[NVB][E];
 #pragma unroll
@@ -398,7 +446,8 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; vv[c][j] = aw[c][j]; }
         }
         // ---- odd bins
-        F::template runN<false, NVB, 0>(vv, lds, t, ltw);
+        if constexpr (SPR) F::template runN<false, NVB, 0>(vv, lds, t, ltw, [&](auto k) { ld_an(k, E / 2); });
+        else F::template runN<false, NVB, 0>(vv, lds, t, ltw);
         STAMP(1, it, 5);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -406,7 +455,15 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
         }
         STAMP(1, it, 6);
-        F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+        if constexpr (SPR) {
+            F::template runN<true, NVB, X1>(vv, lds, t, ltw, [&](auto k) {
+                constexpr int K = decltype(k)::value;
+#pragma unroll
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = loadb<T, NVB>(pen + NVB * TPB * j);
+            });
+        } else {
+            F::template runN<true, NVB, X1>(vv, lds, t, ltw);
+        }
         STAMP(1, it, 7);
         if (active) {
 #pragma unroll
@@ -554,7 +611,7 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
     cplx<T>* lds0 = reinterpret_cast<cplx<T>*>(smem);
     const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
     cplx<T>* lds = lds0 + (size_t)g * STRIDE;
-    const int i0 = blockIdx.x * G;
+    const int i0 = xcd_row_group<G>(blockIdx.x, gridDim.x) * G;      // 8192-point fp64 rows: G = 2, 32-byte pieces
     const int bl = blockIdx.y, band = band0 + bl;
     const size_t rowoff = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
     const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
@@ -616,17 +673,32 @@ struct FwdP {
     static constexpr bool OK = E == 16 && LDS <= (size_t)160 * 1024;
 };
 
-template <typename T, int L, int PAR>
+template <typename T, int L, int PAR, int K, int NIT, typename Hook>
+__device__ __forceinline__ void post_steps(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1, cplx<T>* Tp, int nx,
+                                           int bi, const Hook& hook);
+// hook(PassIdx<k>): called at the top of sweep step k (the kernel issues a slice of the next tile's loads there)
+template <typename T, int L, int PAR, typename Hook = NoPassHook>
 __device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1,
-                                          cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi) {
+                                          cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
+                                          const Hook& hook = Hook()) {
     using P = FwdP<T, L>;
-    using F = typename P::F;
     constexpr int NVB = P::NVB;
     constexpr int NBP = PAR ? P::NBO : P::NBE;
     constexpr int NIT = (NBP + P::BSTEP - 1) / P::BSTEP;
     cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * NVB;
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
+    post_steps<T, L, PAR, 0, NIT>(zr, ltm, wq1, Tp, nx, bi, hook);
+}
+
+template <typename T, int L, int PAR, int K, int NIT, typename Hook>
+__device__ __forceinline__ void post_steps(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1, cplx<T>* Tp, int nx,
+                                           int bi, const Hook& hook) {
+    using P = FwdP<T, L>;
+    using F = typename P::F;
+    constexpr int NVB = P::NVB;
+    constexpr int NBP = PAR ? P::NBO : P::NBE;
+    if constexpr (K < NIT) {
+        constexpr int k = K;
+        hook(PassIdx<K>{});
         int b = bi + k * P::BSTEP;
         if (b >= NBP) b = NBP - 1;                 // clamped: duplicates of the last block, same data
         Blk<T, NVB> o;
@@ -646,10 +718,13 @@ __device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm,
         }
         storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
         __builtin_amdgcn_sched_barrier(0);         // keep the sweeps' LDS reads from piling up (spills)
+        post_steps<T, L, PAR, K + 1, NIT, Hook>(zr, ltm, wq1, Tp, nx, bi, hook);
     }
 }
 
-template <typename T, int L, bool BEAM>
+// SPR: the next tile's rows are requested two at a time inside the even-bin sweep (its beam rows inside the odd-bin
+// sweep) instead of in one burst before it: the burst parks all 16 waves at issue (profiles/r02_a_phase_stamps_*).
+template <typename T, int L, bool BEAM, bool SPR = false>
 __global__ void __launch_bounds__(1024)
 k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
@@ -711,19 +786,34 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
 #pragma unroll
             for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[0][j];
             // next tile's rows: in flight during both post-processing sweeps
-            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
-            const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
+            if constexpr (!SPR) {
+                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
 #pragma unroll
-            for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+                for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+            }
             __syncthreads();
         }
         STAMP(0, sit, 3);
+        constexpr int NITE_ = (P::NBE + P::BSTEP - 1) / P::BSTEP, NITO_ = (P::NBO + P::BSTEP - 1) / P::BSTEP;
         {
             const int tid = launder((int)threadIdx.x);
-            fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            if constexpr (SPR) {
+                const int g = tid / TPB, t = tid % TPB;
+                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
+                fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G,
+                                   [&](auto k) {
+                                       constexpr int K = decltype(k)::value;
+#pragma unroll
+                                       for (int j = (K * E) / NITE_; j < ((K + 1) * E) / NITE_; ++j) xa[j] = xr[TPB * j];
+                                   });
+            } else {
+                fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            }
         }
         STAMP(0, sit, 4);
-        if constexpr (BEAM) {           // the next tile's beam rows: requested once the even-bin registers are free
+        if constexpr (BEAM && !SPR) {   // the next tile's beam rows: requested once the even-bin registers are free
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB;
             const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
@@ -740,7 +830,18 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[1][j];
             __syncthreads();
             STAMP(0, sit, 5);
-            fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            if constexpr (BEAM && SPR) {
+                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const V2* br = reinterpret_cast<const V2*>(beam + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
+                fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G,
+                                   [&](auto k) {
+                                       constexpr int K = decltype(k)::value;
+#pragma unroll
+                                       for (int j = (K * E) / NITO_; j < ((K + 1) * E) / NITO_; ++j) ba[j] = br[TPB * j];
+                                   });
+            } else {
+                fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            }
             STAMP(0, sit, 6);
             __syncthreads();                                     // rows free for the next transform
         }
@@ -838,13 +939,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     // XCD-aware row-group order: with G = 4 a 128-byte line of T is shared by two row groups;
     // workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2 --
     // give THEM the two halves of a line (speed only, any mapping is correct).
-    int rg = blockIdx.x;
-    if constexpr (G * (int)sizeof(cplx<T>) * FastCfg<T>::NVB < 128) {
-        if ((gridDim.x & 15) == 0) {
-            const int q = blockIdx.x >> 4, rem = blockIdx.x & 15;
-            rg = 2 * (q * 8 + (rem & 7)) + (rem >> 3);
-        }
-    }
+    const int rg = xcd_row_group<G>(blockIdx.x, gridDim.x);
     const int i0 = rg * G;
     const int bl = blockIdx.y, band = band0 + bl;
     const cplx<T>* Tb = Tw + (size_t)band * d.T_band;
@@ -959,6 +1054,21 @@ __device__ __forceinline__ void inv_issue(const cplx<T>* __restrict__ Tb, int nx
     }
 }
 
+// loads [K0, K1) of the same set (a compile-time slice: one FFT pass issues a few of them, see RegFft's pass hook)
+template <typename T, int L, int E, int PAR, int K0, int K1>
+__device__ __forceinline__ void inv_issue_slice(const cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
+                                                Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
+    using P = InvP<T, L, E>;
+    constexpr int NBP = PAR ? P::NBO : P::NBE;
+    const cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * P::NVB;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        int b = bi + k * P::BSTEP;
+        if (b >= NBP) b = NBP - 1;
+        y[k] = loadb<T, P::NVB>(Tp + (size_t)b * nx * P::NVB);
+    }
+}
+
 template <typename T, int L, int E, int PAR>
 __device__ __forceinline__ void inv_scatter(const Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE],
                                             cplx<T>* yr, int bi) {
@@ -995,7 +1105,12 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
 }
 
 // MODE 0: no inner products; 1: <x, out>, <out, out>; 2: also <dot_with2, out> (the PCG call)
-template <typename T, int L, int E, int MODE, bool BEAM>
+// SPR: the strided pieces and the epilogue operands are requested a few per FFT PASS (RegFft pass hook) instead of
+// in two bursts behind the scatters: a burst of 21 loads per thread parks all 16 waves at issue for 7.6 us of a
+// 22.6 us trip (profiles/r02_a_phase_stamps_*).  Per trip, in issue order (vmcnt retires in order):
+//     IFFT (even)  <- y(odd bins of this tile), then x [, beam]   of this tile's rows
+//     IFFT (odd)   <- dot_with2 rows, then y(even bins of the NEXT tile)
+template <typename T, int L, int E, int MODE, bool BEAM, bool SPR = false>
 __global__ void __launch_bounds__((InvP<T, L, E>::NT))
 k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptw, const T* __restrict__ x, const T* __restrict__ beam,
@@ -1005,6 +1120,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     using P = InvP<T, L, E>;
     using F = typename P::F;
     constexpr int TPB = F::TPB, G = P::G, NT = P::NT;
+    constexpr int NP = F::NPASS, NPA = NP / 2 > 0 ? NP / 2 : 1, NPB = NP - NPA > 0 ? NP - NPA : 1;
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* red = reinterpret_cast<double*>(smem);
@@ -1039,6 +1155,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
         cplx<T> vv[E], ev[P::PARK ? 1 : E];
+        V2 xq[E], rq[MODE == 2 ? E : 1], bq[BEAM ? E : 1];
         // ---- even bins
         {
             const int tid = launder((int)threadIdx.x);
@@ -1048,12 +1165,31 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             STAMP(2, sit, 1);
             inv_scatter<T, L, E, 0>(y, lds0 + (size_t)rr * P::STRIDE, bi);
             STAMP(2, sit, 2);
-            inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
+            if constexpr (!SPR) inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
             __syncthreads();
             STAMP(2, sit, 3);
             inv_build<T, L, E, 0>(lds, ltm, wq1, t, vv);
             STAMP(2, sit, 4);
-            F::template run<true>(vv, lds, t, ltw);
+            if constexpr (SPR) {
+                const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+                const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+                const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
+                F::template run<true>(vv, lds, t, ltw, [&](auto k) {
+                    constexpr int K = decltype(k)::value;
+                    if constexpr (K < NPA) {            // first passes: the odd-bin pieces (needed first)
+                        inv_issue_slice<T, L, E, 1, (K * P::NITO) / NPA, ((K + 1) * P::NITO) / NPA>(Tb, d.nx, i0, rr, bi, y);
+                    } else {                            // then this tile's x (and beam) rows for the epilogue
+                        constexpr int KK = K - NPA;
+#pragma unroll
+                        for (int j = (KK * E) / NPB; j < ((KK + 1) * E) / NPB; ++j) {
+                            xq[j] = xr[TPB * j];
+                            if constexpr (BEAM) bq[j] = br[TPB * j];
+                        }
+                    }
+                });
+            } else {
+                F::template run<true>(vv, lds, t, ltw);
+            }
             STAMP(2, sit, 5);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -1061,7 +1197,6 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             }
         }
         // ---- odd bins
-        V2 xq[E], rq[E], bq[BEAM ? E : 1];
         {
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
@@ -1071,24 +1206,44 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             inv_scatter<T, L, E, 1>(y, lds0 + (size_t)rr * P::STRIDE, bi);
             STAMP(2, sit, 7);
             const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
-            const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
             const V2* dr2 = reinterpret_cast<const V2*>(dot_with2 + rowoff) + t;
+            const cplx<T>* Tbn = Tw + (size_t)(band0 + bln) * d.T_band;
+            if constexpr (!SPR) {
+                const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                xq[j] = xr[TPB * j];
-                if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
-            }
-            if constexpr (BEAM) {
-                const V2* br = reinterpret_cast<const V2*>(beam + rowoff) + t;
+                for (int j = 0; j < E; ++j) {
+                    xq[j] = xr[TPB * j];
+                    if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
+                }
+                if constexpr (BEAM) {
+                    const V2* br = reinterpret_cast<const V2*>(beam + rowoff) + t;
 #pragma unroll
-                for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
+                    for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
+                }
+                inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
             }
-            inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, rr, bi, y);
             __syncthreads();
             STAMP(2, sit, 8);
             inv_build<T, L, E, 1>(lds, ltm, wq1, t, vv);
             STAMP(2, sit, 9);
-            F::template run<true>(vv, lds, t, ltw);
+            if constexpr (SPR) {
+                F::template run<true>(vv, lds, t, ltw, [&](auto k) {
+                    constexpr int K = decltype(k)::value;
+                    if constexpr (MODE == 2) {
+                        if constexpr (K < NPA) {        // dot_with2 rows first: the epilogue waits for them
+#pragma unroll
+                            for (int j = (K * E) / NPA; j < ((K + 1) * E) / NPA; ++j) rq[j] = dr2[TPB * j];
+                        } else {                        // the next tile's even-bin pieces stay in flight past the epilogue
+                            constexpr int KK = K - NPA;
+                            inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
+                        }
+                    } else {
+                        inv_issue_slice<T, L, E, 0, (K * P::NITE) / NP, ((K + 1) * P::NITE) / NP>(Tbn, d.nx, i0n, rr, bi, y);
+                    }
+                });
+            } else {
+                F::template run<true>(vv, lds, t, ltw);
+            }
             STAMP(2, sit, 10);
         }
         // ---- z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
@@ -1205,7 +1360,9 @@ static int set_invp_attr() {
     constexpr int E = RowCfg<T, L, true>::E;
     if constexpr (InvP<T, L, E>::OK) {
 #define PFB_INVATTR(MODE, BM)                                                                           \
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_inv_pow2p<T, L, E, MODE, BM>),             \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_inv_pow2p<T, L, E, MODE, BM, false>),      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_inv_pow2p<T, L, E, MODE, BM, true>),       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
         PFB_INVATTR(0, false); PFB_INVATTR(1, false); PFB_INVATTR(2, false);
         PFB_INVATTR(0, true);  PFB_INVATTR(1, true);  PFB_INVATTR(2, true);
@@ -1219,9 +1376,13 @@ static int prep_fwdp(void** table) {
     if constexpr (FwdP<T, L>::OK) {
         int rc = prep_ptw_compact<T, L, FwdP<T, L>::EOK>(table);
         if (rc != PFB_OK) return rc;
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, false>),
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, false, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, true>),
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return PFB_OK;
@@ -1276,7 +1437,8 @@ bool pow2_supported(const pfb_conv_plan* p) {
     if (!is_pow2(p->nx) || !is_pow2(p->ny)) return false;
     if (p->P != 2 * p->nx || p->Q != 2 * p->ny) return false;
     if (p->nx < 64 || p->nx > 8192) return false;
-    if (p->ny < 128 || p->ny > 16384) return false;
+    // rows: one length-ny/2 complex transform per image row in LDS: 8192 complex64 (ny = 16384) fit, complex128 do not
+    if (p->ny < 128 || p->ny > (p->dtype == PFB_F32 ? 16384 : 8192)) return false;
     return true;
 }
 
@@ -1428,17 +1590,18 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
         // 0.96 ms at 8 x 4096^2 fp32, 1.16 -> 1.10 ms at 4 x 4096^2 fp64; with two workgroups per CU (H = 2048)
         // the doubled LDS costs residency (fp64 0.245 -> 0.304 ms).  PFB_COL_DB=0 turns it off.
         static const bool db_on = [] { const char* e = getenv("PFB_COL_DB"); return !e || atoi(e); }();
+        // loads spread over the FFT passes (see the kernel); PFB_SPREAD=0 keeps the two-burst schedule (A/B)
+        static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
         const size_t tab = sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1);
-        if (db_on && wg_per_cu == 1 && 2 * lds + tab <= (size_t)160 * 1024)
-            hipLaunchKernelGGL((k_col_pow2p<T, H, E, true>), dim3(grid), dim3(GC * F::TPB), 2 * lds + tab, st,
-                               (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
-                               (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
-                               p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);
-        else
-            hipLaunchKernelGGL((k_col_pow2p<T, H, E, false>), dim3(grid), dim3(GC * F::TPB), lds + tab, st,
-                               (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,
-                               (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,
-                               p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);
+        const bool db = db_on && wg_per_cu == 1 && 2 * lds + tab <= (size_t)160 * 1024;
+#define PFB_COLP(DBV, SPV)                                                                                     \
+        hipLaunchKernelGGL((k_col_pow2p<T, H, E, DBV, SPV>), dim3(grid), dim3(GC * F::TPB), (DBV ? 2 : 1) * lds + tab, st, \
+                           (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,                   \
+                           (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,                    \
+                           p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1)
+        if (db) { if (spread) PFB_COLP(true, true); else PFB_COLP(true, false); }
+        else    { if (spread) PFB_COLP(false, true); else PFB_COLP(false, false); }
+#undef PFB_COLP
         return;
     }
     hipLaunchKernelGGL((k_col_pow2<T, H, E>), dim3((nblk + GC - 1) / GC, nb), dim3(GC * F::TPB), lds, st,
@@ -1453,9 +1616,13 @@ static int col_set_attr_t(int H) {
 #define X(NN) case NN:                                                                                        \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2<T, NN, ecol<T, NN>()>),                    \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false>),            \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false, false>),     \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
-        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true>),             \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true, false>),      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false, true>),      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true, true>),       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_fwd_pow2<T, NN, ecol<T, NN>()>),                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
@@ -1528,14 +1695,16 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, void* Tbuf, i
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
-            if (beam)
-                hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, true>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
-                                   (const T*)beam, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,
-                                   (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
-            else
-                hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, false>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x,
-                                   (const T*)nullptr, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,
-                                   (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1);
+            // spreading the next tile's row requests over the even-bin sweep measured SLOWER here (0.389 -> 0.411 ms at
+            // 8 x 4096^2 fp32: the sweep's stores and the loads then queue behind each other): off unless PFB_SPREAD_FWD=1
+            static const bool spread = [] { const char* e = getenv("PFB_SPREAD_FWD"); return e && atoi(e); }();
+#define PFB_FWDP(BM, SP)                                                                                          \
+            hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, BM, SP>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x, \
+                               (const T*)beam, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,                          \
+                               (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1)
+            if (beam) { if (spread) PFB_FWDP(true, true); else PFB_FWDP(true, false); }
+            else      { if (spread) PFB_FWDP(false, true); else PFB_FWDP(false, false); }
+#undef PFB_FWDP
             return;
         }
     }
@@ -1562,12 +1731,14 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
-#define PFB_INVP2(MODE, BM)                                                                             \
-            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE, BM>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
+            static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
+#define PFB_INVP3(MODE, BM, SP)                                                                         \
+            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE, BM, SP>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
                                (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
                                (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam,            \
                                (const T*)dot_with2, (T*)out, p->partials, d, band0, tiles_per_band,     \
                                ntiles, (T)scale, (T)sigmainv, wq1)
+#define PFB_INVP2(MODE, BM) do { if (spread) PFB_INVP3(MODE, BM, true); else PFB_INVP3(MODE, BM, false); } while (0)
 #define PFB_INVP(MODE) do { if (beam) PFB_INVP2(MODE, true); else PFB_INVP2(MODE, false); } while (0)
             p->last_npartials = grid;
             if (!dot_with) PFB_INVP(0);
@@ -1575,6 +1746,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
             else PFB_INVP(2);
 #undef PFB_INVP
 #undef PFB_INVP2
+#undef PFB_INVP3
             return;
         }
     }

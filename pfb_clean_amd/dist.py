@@ -41,14 +41,18 @@ class AllReduceHook:
         self.work = work
         self.group = group
         self.calls = 0
+        self.host_s = 0.0            # host time spent inside the hook (enqueue of the collective), for bench.py
 
     def __call__(self, addr, count):
+        import time
+        t0 = time.perf_counter()
         off = addr - self.work.data_ptr()
         if off < 0 or off + 8 * count > self.work.numel() * self.work.element_size():
             raise ValueError("allreduce buffer outside the solver workspace")
         view = self.work.view(torch.uint8)[off:off + 8 * count].view(torch.float64)
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
+        self.host_s += time.perf_counter() - t0
 
 
 def global_max(value, device, group=None):

@@ -100,6 +100,8 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
 @pmp('size', SIZES)
 def test_conv_vs_oracle_sizes(amd, size, rdt):
     nx, ny, P, Q = size
+    if ny > 8192 and rdt == np.float64:
+        pytest.skip("fp64 rows of ny > 8192 pixels do not fit the LDS (documented limit: DESIGN 4.1)")
     rng = np.random.default_rng(nx * 1000 + ny)
     nb = 2
     psf = rng.standard_normal((nb, P, Q))

@@ -313,7 +313,7 @@ def test_cg_dct_nested_dict(kind):
                                    # power-of-two: the fast path's row / column kernels (largest column / row lines)
                                    (2, 2048, 1024), (1, 16384, 256), (1, 128, 16384),
                                    # lines beyond the LDS, not powers of two: global-memory Stockham passes
-                                   (1, 12000, 96), (1, 96, 28800), (1, 14400, 128)])
+                                   (1, 12000, 96), (1, 96, 12000), (1, 14400, 128)])
 def test_native_psfhat_producer(shape, rdt):
     """pfb_psfconv_set_psf (gridder.py:712-714: r2c(ifftshift(psf))) against the oracle, pow2 and
     mixed-radix grids, odd nx_psf; and a plan built straight from the PSF convolves like one built
@@ -568,12 +568,16 @@ def test_new_entry_points_reject_bad_arguments():
         hogbom(np.ones((2, 16, 16)), np.zeros((2, 32, 32)), verbosity=0)     # PSF peaks must be positive
     with pytest.raises(AssertionError):
         clark(np.ones((2, 16, 16)), np.ones((2, 32, 32)), np.ones((2, 32, 17), complex), np.array([0.7, 0.7]), verbosity=0)
-    # regrid: target grid too small for the image, and a line that does not fit the LDS
+    # regrid: target grid too small for the image, and a grid length with a prime factor > 13 (every buffer is
+    # sized for the call, so that nothing is out of bounds should a check ever go missing)
     ph = torch.zeros((1, 32, 17), dtype=torch.complex128, device=dev)
-    out = torch.zeros((1, 32, 17), dtype=torch.complex128, device=dev)
+    out = torch.zeros((1, 34, 18), dtype=torch.complex128, device=dev)
     assert lib.pfb_psfhat_regrid(1, _dev.ptr(ph), 1, 20, 20, 32, 32, 32, 32, _dev.ptr(out), _dev.stream()) == -1
-    assert lib.pfb_psfhat_regrid(1, _dev.ptr(ph), 1, 8, 8, 32, 32, 16384, 32, _dev.ptr(out), _dev.stream()) \
+    assert lib.pfb_psfhat_regrid(1, _dev.ptr(ph), 1, 8, 8, 32, 32, 34, 34, _dev.ptr(out), _dev.stream()) \
         == _lib.PFB_ERR_UNSUPPORTED
+    psf17 = torch.zeros((1, 34, 34), dtype=torch.float64, device=dev)
+    assert lib.pfb_psfhat_from_psf(1, _dev.ptr(psf17), 1, 34, 34, _dev.ptr(out), _dev.stream()) == _lib.PFB_ERR_UNSUPPORTED
+    assert lib.pfb_psfhat_from_psf(1, _dev.ptr(psf17), 1, 34, 33, _dev.ptr(out), _dev.stream()) == _lib.PFB_ERR_UNSUPPORTED
     x = torch.zeros((2, 4, 4), dtype=torch.float64, device=dev)
     A = torch.eye(2, dtype=torch.float64, device=dev)
     assert lib.pfb_freqmul(1, _dev.ptr(A), _dev.ptr(x), _dev.ptr(x), 2, 16, None, None, _dev.stream()) == -1   # aliasing
