@@ -63,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline / parity leg')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--cpu-cores', type=int, default=0,
-                    help='host cores for the cpu_baseline leg (0 = the CPU share of this process, at most 16 per GPU)')
+                    help='host cores for the cpu_baseline leg (0 = min(usable cores, 64): the fastest setting measured)')
     ap.add_argument('--force-dist', action='store_true',
                     help='run the band-sharded code path (all-reduce hook) even at world size 1')
     ap.add_argument('--cpu-worker', nargs=5, metavar=('DIR', 'BAND', 'THREADS', 'ITERS', 'SIGMAINV'),
@@ -143,6 +143,23 @@ def synth_model(band, nx, ny, dtype, device):
     return model.to(dtype)
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; rank 0's stdout must carry
+    exactly one JSON line, so file descriptor 1 points at stderr while the process group warms up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _median(v):
     s = sorted(v)
     n = len(s)
@@ -163,14 +180,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     use_pg = world > 1 or args.force_dist
-    if use_pg:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        # RCCL in production; PFB_DIST_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 path
-        dist.init_process_group(os.environ.get('PFB_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
     ndev = torch.cuda.device_count()
     torch.cuda.set_device(local_rank % max(ndev, 1))
     device = torch.device('cuda', local_rank % max(ndev, 1))
+    if use_pg:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        with _stdout_to_stderr():
+            # RCCL in production; PFB_DIST_BACKEND=gloo lets a 1-GPU box rehearse the N > 1 path
+            dist.init_process_group(os.environ.get('PFB_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+            t = torch.zeros(1, device=device)
+            dist.all_reduce(t)                     # brings the communicator up (and its banner out) here
+            torch.cuda.synchronize()
     ctx = dict(args=args, world=world, rank=rank, device=device, use_pg=use_pg)
     out = bench_pd(ctx) if args.workload == 'pd' else bench_pcg(ctx)
     if rank == 0:
@@ -326,8 +347,9 @@ def _cpu_share(args):
         avail = os.cpu_count() or 1
     if args.cpu_cores > 0:
         return min(args.cpu_cores, avail), avail
-    # a one-GPU box's share of its host is 16 cores (the gpurun contract); never more than we may use
-    return min(16, avail), avail
+    # 8 bands x 8 FFT workers: the fastest setting of a sweep on the 256-core MI355X host (16 cores 1.90, 64 cores
+    # 2.28, 256 cores 0.90 cube-matvecs/s: scipy.fft stops scaling and the bands start to fight over memory)
+    return min(64, avail), avail
 
 
 def cpu_worker(d, band, threads, iters, sigmainv):

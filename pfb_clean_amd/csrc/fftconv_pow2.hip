@@ -269,13 +269,28 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
     }
+    // 8192-point fp64 columns: one 512-thread workgroup per CU (its exchange buffer fills the LDS; the persistent
+    // kernel's twiddle table no longer fits) and 256 VGPRs per thread: psf_e is requested BEFORE the first transform and
+    // psf_o before the second, so that two of the three HBM latencies of a block hide behind a transform
+    // (2.97 -> see DESIGN 5 ms per 2 bands).  Elsewhere (128-VGPR cap) the loads stay behind the transforms.
+    constexpr bool PREQ = false && sizeof(T) == 8 && H >= 8192;
+    Blk<T, NVB> q[PREQ ? E : 1];
+    if constexpr (PREQ) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
+    }
     // ---- even bins of the column transform
     F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const Blk<T, NVB> p = loadb<T, NVB>(pe + NVB * TPB * j);
+        Blk<T, NVB> p;
+        if constexpr (PREQ) p = q[j]; else p = loadb<T, NVB>(pe + NVB * TPB * j);
 #pragma unroll
         for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
+    }
+    if constexpr (PREQ) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
     }
     F::template runN<true, NVB>(vv, lds, t, ptw);
     cplx<T> ev[NVB][E];
@@ -288,7 +303,8 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
-        const Blk<T, NVB> p = loadb<T, NVB>(po + NVB * TPB * j);
+        Blk<T, NVB> p;
+        if constexpr (PREQ) p = q[j]; else p = loadb<T, NVB>(po + NVB * TPB * j);
 #pragma unroll
         for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
     }
@@ -851,6 +867,127 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     }
 }
 
+// ------------------------------------------- row forward, persistent, parities in sequence
+// k_row_fwd_pow2p above runs the even-bin and the odd-bin transform of a tile together and then the two
+// post-processing sweeps; the next tile's rows are requested in one burst between them, which parks all 16 waves at
+// issue (profiles/r02_a_phase_stamps_*: 8.0 of 28 us per trip, and the 9.3 us of the transforms run with NOTHING in
+// flight).  Here the parities run one after the other:
+//     z = x [* beam]              -> FFT  -> LDS -> even-bin sweep (stores)
+//     z .* w_M^n  (x now dead)    -> FFT  -> LDS -> odd-bin sweep  (stores)
+// and the next tile's rows are requested a few per PASS of the second transform INTO THE REGISTERS THE CURRENT ROWS
+// JUST LEFT (no extra registers): the even-bin sweep's stores drain and the next rows arrive while the second
+// transform computes, the odd-bin sweep's stores drain during the next tile's first transform.
+template <typename T, int L, bool BEAM>
+__global__ void __launch_bounds__(1024)
+k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
+                const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
+                cplx<T> wq1) {
+    using P = FwdP<T, L>;
+    constexpr int E = P::EOK;
+    using F = RegFft<T, L, E, false, 0, true, false>;        // one transform at a time, twiddles from LDS
+    constexpr int TPB = F::TPB, G = P::G, NT = P::NT, NP = F::NPASS;
+    using V2 = typename vec2<T>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* ltm = ltw + P::PTWP;
+    cplx<T>* lds0 = ltm + L;
+    int vb = blockIdx.x;
+    if (vb >= ntiles) return;
+    for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptwc[k];
+    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    V2 xa[E], ba[BEAM ? E : 1];
+    {
+        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
+        const size_t off = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
+        const V2* xr = reinterpret_cast<const V2*>(x + off) + t;
+#pragma unroll
+        for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
+        if constexpr (BEAM) {
+            const V2* br = reinterpret_cast<const V2*>(beam + off) + t;
+#pragma unroll
+            for (int j = 0; j < E; ++j) ba[j] = br[TPB * j];
+        }
+    }
+    __syncthreads();                                    // tables visible
+    for (int sit = 0;; ++sit) {
+        STAMP(0, sit, 0);
+        const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
+        cplx<T> vv[E];
+        // ---- even bins: z[n] = x[2n] + i x[2n+1]
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                if constexpr (BEAM) { xa[j].x *= ba[j].x; xa[j].y *= ba[j].y; }
+                vv[j] = cplx<T>(xa[j].x, xa[j].y);
+            }
+            STAMP(0, sit, 1);
+            F::template run<false>(vv, lds, t, ltw);
+            STAMP(0, sit, 2);
+        }
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            __syncthreads();                                     // last exchange's readers are done
+            cplx<T>* wp = lds0 + (size_t)g * P::STRIDE + F::pad(t);
+#pragma unroll
+            for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[j];
+            __syncthreads();
+        }
+        STAMP(0, sit, 3);
+        {
+            const int tid = launder((int)threadIdx.x);
+            fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+        }
+        STAMP(0, sit, 4);
+        // ---- odd bins: z .* w_M^n; the rows die here and their registers take the NEXT tile's rows
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                vv[j] = cplx<T>(xa[j].x, xa[j].y) * ltm[t + TPB * j];
+                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+            const size_t offn = (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch;
+            const V2* xr = reinterpret_cast<const V2*>(x + offn) + t;
+            const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + offn) + t : nullptr;
+            // the first exchange of this transform waits (barrier) for the even-bin sweep's LDS reads
+            F::template run<false>(vv, lds, t, ltw, [&](auto k) {
+                constexpr int K = decltype(k)::value;
+#pragma unroll
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) {
+                    xa[j] = xr[TPB * j];
+                    if constexpr (BEAM) ba[j] = br[TPB * j];
+                }
+            });
+            STAMP(0, sit, 5);
+        }
+        {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            cplx<T>* wp = lds0 + (size_t)g * P::STRIDE + F::pad(t);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[j];
+            __syncthreads();
+            fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
+            STAMP(0, sit, 6);
+            __syncthreads();                                     // rows free for the next transform
+        }
+        STAMP(0, sit, 7);
+        if (vbn == vb) break;
+        vb = vbn;
+    }
+}
+
 // ------------------------------------------------------------------- row inverse
 // one parity of the inverse row transform: gathers Y[2m + PAR][i0 .. i0+G) (G*8-byte
 // pieces), LDS-transposes them to per-row order, builds the packed spectrum and runs
@@ -1384,6 +1521,10 @@ static int prep_fwdp(void** table) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2p<T, L, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2q<T, L, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_fwd_pow2q<T, L, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     return PFB_OK;
 }
@@ -1697,6 +1838,17 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, void* Tbuf, i
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
             // spreading the next tile's row requests over the even-bin sweep measured SLOWER here (0.389 -> 0.411 ms at
             // 8 x 4096^2 fp32: the sweep's stores and the loads then queue behind each other): off unless PFB_SPREAD_FWD=1
+            // parities in sequence, next rows requested inside the second transform (k_row_fwd_pow2q); PFB_FWD_SEQ=0: A/B
+            static const bool seq = [] { const char* e = getenv("PFB_FWD_SEQ"); return !e || atoi(e); }();
+            if (seq) {
+#define PFB_FWDQ(BM)                                                                                              \
+                hipLaunchKernelGGL((k_row_fwd_pow2q<T, L, BM>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x, \
+                                   (const T*)beam, (cplx<T>*)Tbuf, (const cplx<T>*)ft->twM,                      \
+                                   (const cplx<T>*)ft->ptwc_row_fwd, d, band0, tiles_per_band, ntiles, wq1)
+                if (beam) PFB_FWDQ(true); else PFB_FWDQ(false);
+#undef PFB_FWDQ
+                return;
+            }
             static const bool spread = [] { const char* e = getenv("PFB_SPREAD_FWD"); return e && atoi(e); }();
 #define PFB_FWDP(BM, SP)                                                                                          \
             hipLaunchKernelGGL((k_row_fwd_pow2p<T, L, BM, SP>), dim3(grid), dim3(FP::NT), FP::LDS, st, (const T*)x, \
