@@ -73,6 +73,33 @@ __device__ __forceinline__ void st(T* p, size_t i, const Pack<T, V>& r) {
     }
 }
 
+// non-temporal forms (global_load / global_store ... nt) for streams that are touched once per iteration and are not
+// re-read before ~256 MiB of other traffic has passed: they should not displace what IS re-read soon (at one band per
+// GPU the half spectrum T, p and A p live in the Infinity Cache between kernels)
+template <typename T, int V>
+__device__ __forceinline__ Pack<T, V> ld_nt(const T* p, size_t i) {
+    Pack<T, V> r;
+    if constexpr (V == 1) {
+        r.e[0] = __builtin_nontemporal_load(p + i);
+    } else {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p) + i);
+        memcpy(&r, &v, 16);
+    }
+    return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void st_nt(T* p, size_t i, const Pack<T, V>& r) {
+    if constexpr (V == 1) {
+        __builtin_nontemporal_store(r.e[0], p + i);
+    } else {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v;
+        memcpy(&v, &r, 16);
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(p) + i);
+    }
+}
+
 // write NQ block results to ws[q * gridDim.x + blockIdx.x]
 template <int NQ>
 __device__ __forceinline__ void emit_partials(double (&acc)[NQ], double* __restrict__ ws) {
@@ -256,7 +283,8 @@ k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__
 // so beta = rho(alpha)/rho is available up front (the reference forms beta from the recomputed
 // <r',y'>; the two differ by rounding only -- the recomputed value is still what the NEXT
 // iteration uses as rnorm).  sums: <r',y'>, |x'-x|^2, |x'|^2, count(p' != 0)
-template <typename T, int V, int U = 1>
+// XNT: x is read and x' written non-temporally (x is not touched again until the next update, ~20 N bytes later)
+template <typename T, int V, int U = 1, bool XNT = false>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ p,
                  const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
@@ -271,7 +299,7 @@ k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict
 #pragma unroll
         for (int u = 0; u < U; ++u) {              // all loads of the U strips in flight together
             const size_t i = i0 + u * stride;
-            if (i < nvec) { px[u] = ld<T, V>(x, i); pr[u] = ld<T, V>(r, i); pp[u] = ld<T, V>(p, i); pa[u] = ld<T, V>(Ap, i); }
+            if (i < nvec) { px[u] = XNT ? ld_nt<T, V>(x, i) : ld<T, V>(x, i); pr[u] = ld<T, V>(r, i); pp[u] = ld<T, V>(p, i); pa[u] = ld<T, V>(Ap, i); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -295,7 +323,7 @@ k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict
                 }
                 acc[3] += (pp[u].e[e] != T(0)) ? 1.0 : 0.0;
             }
-            st<T, V>(xn, i, ox);
+            if constexpr (XNT) st_nt<T, V>(xn, i, ox); else st<T, V>(xn, i, ox);
             st<T, V>(rn, i, orr);
             if (!dead) st<T, V>(p, i, pp[u]);
         }
@@ -521,7 +549,10 @@ static int launch_update_dir(size_t n, const T* x, const T* r, T* p, const T* Ap
     if (can_vec<T>(n, PL{x, r, p, Ap, xn, rn})) {
         const size_t nvec = n / V;
         const int G = stream_grid(nvec);
-        if (unroll == 2)
+        static const bool xnt = [] { const char* e = getenv("PFB_UPD_XNT"); return !e || atoi(e); }();
+        if (unroll == 2 && xnt)
+            hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2, true>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
+        else if (unroll == 2)
             hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
         else
             hipLaunchKernelGGL((k_pcg_update_dir<T, V, 1>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);

@@ -130,6 +130,19 @@ template <typename T, int NVB>
 __device__ __forceinline__ Blk<T, NVB> loadb(const cplx<T>* src) {
     return *reinterpret_cast<const Blk<T, NVB>*>(src);
 }
+// the same, marked non-temporal (global_load ... nt): for streams that are read exactly once per launch and are far
+// larger than the 256 MiB Infinity Cache (the PSF spectrum: 268 MB per 4096^2 fp32 band) -- they should not push
+// the half-spectrum T, which the NEXT kernel re-reads, out of it
+template <typename T, int NVB>
+__device__ __forceinline__ Blk<T, NVB> loadb_nt(const cplx<T>* src) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(Blk<T, NVB>) == 16, "16-byte blocks");
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+    Blk<T, NVB> b;
+    __builtin_memcpy(&b, &v, 16);
+    return b;
+}
+
 template <typename T, int NVB>
 __device__ __forceinline__ void storeb(cplx<T>* dst, const Blk<T, NVB>& b) {
     *reinterpret_cast<Blk<T, NVB>*>(dst) = b;
@@ -339,7 +352,7 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 //     IFFT (even)  <- psf_o of this item
 //     FFT (odd)    <- second half of the next item's a         multiply by psf_o
 //     IFFT (odd)   <- psf_e of the NEXT item
-template <typename T, int H, int E, bool DB = false, bool SPR = false>
+template <typename T, int H, int E, bool DB = false, bool SPR = false, bool NT = false>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), 2)
 k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
@@ -389,7 +402,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         if constexpr (SPR) {
             const cplx<T>* pe0 = psf_of(act ? item : 0);
 #pragma unroll
-            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe0 + NVB * TPB * j);
+            for (int j = 0; j < E; ++j) q[j] = NT ? loadb_nt<T, NVB>(pe0 + NVB * TPB * j) : loadb<T, NVB>(pe0 + NVB * TPB * j);
         }
     }
     __syncthreads();                                            // twiddle table visible
@@ -414,7 +427,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         if constexpr (!SPR) {
             // in issue order (vmcnt retires in order): psf_e of this item, then a of the next
 #pragma unroll
-            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
+            for (int j = 0; j < E; ++j) q[j] = NT ? loadb_nt<T, NVB>(pe + NVB * TPB * j) : loadb<T, NVB>(pe + NVB * TPB * j);
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if (nact) an[j] = loadb<T, NVB>(cn + NVB * TPB * j);
@@ -447,11 +460,11 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             F::template runN<true, NVB, X1>(vv, lds, t, ltw, [&](auto k) {
                 constexpr int K = decltype(k)::value;
 #pragma unroll
-                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = NT ? loadb_nt<T, NVB>(po + NVB * TPB * j) : loadb<T, NVB>(po + NVB * TPB * j);
             });
         } else {
 #pragma unroll
-            for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+            for (int j = 0; j < E; ++j) q[j] = NT ? loadb_nt<T, NVB>(po + NVB * TPB * j) : loadb<T, NVB>(po + NVB * TPB * j);
             F::template runN<true, NVB, X1>(vv, lds, t, ltw);
         }
         STAMP(1, it, 4);
@@ -475,7 +488,7 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             F::template runN<true, NVB, X1>(vv, lds, t, ltw, [&](auto k) {
                 constexpr int K = decltype(k)::value;
 #pragma unroll
-                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = loadb<T, NVB>(pen + NVB * TPB * j);
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = NT ? loadb_nt<T, NVB>(pen + NVB * TPB * j) : loadb<T, NVB>(pen + NVB * TPB * j);
             });
         } else {
             F::template runN<true, NVB, X1>(vv, lds, t, ltw);
@@ -1735,8 +1748,16 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
         static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
         const size_t tab = sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1);
         const bool db = db_on && wg_per_cu == 1 && 2 * lds + tab <= (size_t)160 * 1024;
+        // psf read with non-temporal loads (see loadb_nt); PFB_PSF_NT=0: A/B
+        static const bool psf_nt = [] { const char* e = getenv("PFB_PSF_NT"); return !e || atoi(e); }();
 #define PFB_COLP(DBV, SPV)                                                                                     \
-        hipLaunchKernelGGL((k_col_pow2p<T, H, E, DBV, SPV>), dim3(grid), dim3(GC * F::TPB), (DBV ? 2 : 1) * lds + tab, st, \
+        if (SPV && psf_nt)                                                                                     \
+        hipLaunchKernelGGL((k_col_pow2p<T, H, E, DBV, SPV, SPV>), dim3(grid), dim3(GC * F::TPB), (DBV ? 2 : 1) * lds + tab, st, \
+                           (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,                   \
+                           (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,                    \
+                           p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1);                 \
+        else                                                                                                   \
+        hipLaunchKernelGGL((k_col_pow2p<T, H, E, DBV, SPV, false>), dim3(grid), dim3(GC * F::TPB), (DBV ? 2 : 1) * lds + tab, st, \
                            (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,                   \
                            (const cplx<T>*)ft->ptwc_col, nblk, nitems, p->T_elems_per_band,                    \
                            p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1)
@@ -1764,6 +1785,10 @@ static int col_set_attr_t(int H) {
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false, true>),      \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true, true>),       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), false, true, true>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true, true, true>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_fwd_pow2<T, NN, ecol<T, NN>()>),                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
