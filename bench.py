@@ -466,7 +466,7 @@ def bench_pd(ctx):
         raise SystemExit("--workload pd is a one-GPU workload (config #4)")
     from pfb_clean_amd.operators.psf import PsfConvPlan
     from pfb_clean_amd.operators.psi import Psi
-    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised
+    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised, PsfGradient
 
     n = args.size or 2048
     nband = args.bands or 4
@@ -484,10 +484,7 @@ def bench_pd(ctx):
     del model
     psi = Psi(nband, n, n, bases, nlevel, 1, dtype=dtype)
     nbasis = len(bases)
-    conv_out = torch.empty_like(dirty)
-
-    def grad(v):
-        return plan.apply(v, out=conv_out) - dirty          # spotless.py:259-260 (the subtraction is a torch op)
+    grad = PsfGradient(plan, dirty)                          # spotless.py:259-260: conv(x) - dirty
     w = torch.ones((nbasis, psi.Nymax, psi.Nxmax), dtype=dtype, device=device)
     lam = 1e-3 * float(dirty.abs().max().item())
     L = 1.0                                                   # sum_band psf peaks at 1 => ||A^H A|| ~ 1

@@ -250,6 +250,15 @@ int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight,
 int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void* g,
                          double tau, int positivity, int nband, size_t npix,
                          void* x, double* sums, double* ws, void* stream);
+/* The same statement with two fusions (either pointer may be NULL):
+ *   xout_prev: the synthesis term is 2*xout - xout_prev.  psi^H is linear, so psi^H(2 v - vp) of
+ *              primal_dual.py:137-138 equals 2 psi^H(v) - psi^H(vp), and psi^H(vp) is the previous iteration's
+ *              psi^H(v): the caller synthesises v itself and the cube 2 v - vp is never written nor read;
+ *   gsub:      the gradient is g - gsub (grad(x) = conv(x) - dirty, workers/spotless.py:259-260: the data term is
+ *              subtracted here instead of in a pass of its own). */
+int pfb_pd_primal_update2(int dtype, const void* xp, const void* xout, const void* xout_prev, const void* g,
+                          const void* gsub, double tau, int positivity, int nband, size_t npix,
+                          void* x, double* sums, double* ws, void* stream);
 
 /* ------------------------------------------------------------ Clark CLEAN sub-minor loop
  * pfb/deconv/clark.py:29-84 (subminor + subtract).  A: (nband, nact) active-set values, updated

@@ -72,6 +72,7 @@ SIGNATURES = {
     'pfb_freqmul': (_i, [_i, _vp, _vp, _vp, _i, _sz, _vp, _vp, _vp]),
     'pfb_prox_21m': (_i, [_i, _vp, _vp, _vp, _d, _d, _i, _sz, _vp]),
     'pfb_pd_primal_update': (_i, [_i, _vp, _vp, _vp, _d, _i, _i, _sz, _vp, _vp, _vp, _vp]),
+    'pfb_pd_primal_update2': (_i, [_i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _sz, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -805,27 +805,34 @@ k_prox_21m(const T* __restrict__ v, T* __restrict__ res, const T* __restrict__ w
 }
 
 // x = xp - tau (xout + g) ; positivity ; norm_diff partials + any(x)   (primal_dual.py:139-150)
+// xprev (optional): xout is formed as 2 xout - xprev on the fly -- with a LINEAR synthesis psi^H(2 v - vp) =
+// 2 psi^H(v) - psi^H(vp), and psi^H(vp) is the previous iteration's psi^H(v): the coefficient cube 2 v - vp
+// (primal_dual.py:137) is then never written nor read.  gsub (optional): g - gsub is the gradient (the data term of
+// grad(x) = conv(x) - dirty, workers/spotless.py:259-260, subtracted here instead of in a pass of its own).
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_pd_primal(const T* __restrict__ xp, const T* __restrict__ xout, const T* __restrict__ g, T tau,
+k_pd_primal(const T* __restrict__ xp, const T* __restrict__ xout, const T* __restrict__ xprev,
+            const T* __restrict__ g, const T* __restrict__ gsub, T tau,
             int positivity, int nband, size_t npix, T* __restrict__ x, double* __restrict__ ws) {
     __shared__ double red[3 * 4];
     double acc[3] = {0.0, 0.0, 0.0};
+    auto value = [&](size_t k) -> T {
+        T gk = g ? g[k] : T(0);
+        if (gsub) gk -= gsub[k];
+        T xo = xout[k];
+        if (xprev) xo = T(2) * xo - xprev[k];
+        return xp[k] - tau * (xo + gk);
+    };
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
          i += (size_t)gridDim.x * blockDim.x) {
         bool kill = false;
         if (positivity == 2) {
-            for (int b = 0; b < nband; ++b) {
-                const size_t k = (size_t)b * npix + i;
-                const T gk = g ? g[k] : T(0);
-                const T val = xp[k] - tau * (xout[k] + gk);
-                if (val <= T(0)) kill = true;
-            }
+            for (int b = 0; b < nband; ++b)
+                if (value((size_t)b * npix + i) <= T(0)) kill = true;
         }
         for (int b = 0; b < nband; ++b) {
             const size_t k = (size_t)b * npix + i;
-            const T gk = g ? g[k] : T(0);
-            T val = xp[k] - tau * (xout[k] + gk);
+            T val = value(k);
             if (positivity == 1 && val < T(0)) val = 0;
             if (kill) val = 0;
             x[k] = val;
@@ -1556,21 +1563,36 @@ int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight, dou
     return PFB_OK;
 }
 
-int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void* g, double tau,
-                         int positivity, int nband, size_t npix, void* x, double* sums, double* ws,
-                         void* stream) {
+static int pd_primal_launch(int dtype, const void* xp, const void* xout, const void* xprev, const void* g,
+                            const void* gsub, double tau, int positivity, int nband, size_t npix, void* x,
+                            double* sums, double* ws, void* stream) {
     PFB_REQUIRE(xp && xout && x && sums && ws && nband > 0, PFB_ERR_INVALID, "pd_primal_update: bad argument");
+    PFB_REQUIRE(!gsub || g, PFB_ERR_INVALID, "pd_primal_update: gsub given without g");
     hipStream_t st = as_stream(stream);
     const int G = ew_grid(npix) > 1024 ? 1024 : ew_grid(npix);
     if (dtype == PFB_F32)
         hipLaunchKernelGGL((k_pd_primal<float>), dim3(G), dim3(256), 0, st, (const float*)xp, (const float*)xout,
-                           (const float*)g, (float)tau, positivity, nband, npix, (float*)x, ws);
+                           (const float*)xprev, (const float*)g, (const float*)gsub, (float)tau, positivity, nband,
+                           npix, (float*)x, ws);
     else
         hipLaunchKernelGGL((k_pd_primal<double>), dim3(G), dim3(256), 0, st, (const double*)xp,
-                           (const double*)xout, (const double*)g, tau, positivity, nband, npix, (double*)x, ws);
+                           (const double*)xout, (const double*)xprev, (const double*)g, (const double*)gsub, tau,
+                           positivity, nband, npix, (double*)x, ws);
     hipLaunchKernelGGL(k_final_sum3, dim3(1), dim3(256), 0, st, ws, G, 3, sums);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
+}
+
+int pfb_pd_primal_update(int dtype, const void* xp, const void* xout, const void* g, double tau,
+                         int positivity, int nband, size_t npix, void* x, double* sums, double* ws,
+                         void* stream) {
+    return pd_primal_launch(dtype, xp, xout, nullptr, g, nullptr, tau, positivity, nband, npix, x, sums, ws, stream);
+}
+
+int pfb_pd_primal_update2(int dtype, const void* xp, const void* xout, const void* xout_prev, const void* g,
+                          const void* gsub, double tau, int positivity, int nband, size_t npix, void* x,
+                          double* sums, double* ws, void* stream) {
+    return pd_primal_launch(dtype, xp, xout, xout_prev, g, gsub, tau, positivity, nband, npix, x, sums, ws, stream);
 }
 
 }  // extern "C"

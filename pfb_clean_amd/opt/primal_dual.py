@@ -4,12 +4,16 @@ pfb/opt/primal_dual.py:91-180 (primal_dual_optimised).
 
 Per iteration (reference statement -> device work):
     psi(xp, v)                         pfb_psi_dot        (analysis, all bands/bases)
-    dual_update_numba(vp, v, ...)      pfb_dual_update    (fused with vp = 2 v - vp)
-    psiH(vp, xout)                     pfb_psi_hdot       (synthesis)
-    xout += grad(xp)                   caller's callable (one PSF convolution)
-    x = xp - tau xout ; positivity     pfb_pd_primal_update (+ norm_diff sums + any(x))
+    dual_update_numba(vp, v, ...)      pfb_dual_update
+    vp = 2 v - vp ; psiH(vp, xout)     pfb_psi_hdot(v) -> s, and xout = 2 s - s_prev inside the primal update:
+                                       the synthesis is LINEAR, psi^H(2 v - vp) = 2 psi^H(v) - psi^H(vp), and psi^H(vp)
+                                       is the previous iteration's psi^H(v) -- the cube 2 v - vp (primal_dual.py:137)
+                                       is never written nor read (-0.68 GB of 2.1 GB per iteration at config #4)
+    xout += grad(xp)                   caller's callable (one PSF convolution); a PsfGradient object (below) hands
+                                       over conv(x) and the data separately and the subtraction is fused as well
+    x = xp - tau xout ; positivity     pfb_pd_primal_update2 (+ norm_diff sums + any(x))
     eps = norm_diff(x, xp)             from the same kernel's sums
-Everything stays on the GPU; two scalars per iteration come back for the stopping rule.
+Everything stays on the GPU; three scalars per iteration come back for the stopping rule.
 
 Naming trap kept from the reference: the 4th positional `psiH` receives the SYNTHESIS
 operator (Psi.hdot), the 5th `psi` the ANALYSIS operator (Psi.dot) at the call site
@@ -32,6 +36,26 @@ from .. import _lib, _dev
 from ..prox.prox_21m import dual_update_numba
 
 
+class PsfGradient:
+    """grad(x) = psf_convolve_cube(x) - data, the gradient workers/spotless.py:259-260 hands to
+    primal_dual_optimised, as an object: callable like the closure it replaces, and recognised by
+    primal_dual_optimised, which then takes conv(x) and `data` separately and subtracts inside the primal update
+    (one pass over the cube less).  plan: a PsfConvPlan (or psfhat + nx, ny, lastsize through plan_for)."""
+
+    def __init__(self, plan, data):
+        self.plan = plan
+        self.data = _dev.to_dev(data, plan.rdtype).contiguous()
+        self._out = torch.empty_like(self.data)
+
+    def conv(self, x):
+        return self.plan.apply(x, out=self._out)
+
+    def __call__(self, x):
+        xd = _dev.to_dev(x, self.plan.rdtype)
+        res = self.conv(xd) - self.data
+        return res.cpu().numpy() if _dev.is_numpy(x) else res
+
+
 def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, grad,
                           nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000, positivity=1,
                           report_freq=10, gamma=1.0, verbosity=1, maxreweight=50, group=None):
@@ -48,7 +72,11 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     npix = xd[0].numel()
     xp = xd.clone()
     vp = vd.clone()
-    xout = torch.zeros_like(xd)
+    # s_new = psi^H(v) of this iteration, s_old = psi^H(vp) = psi^H(v) of the previous one (linear synthesis)
+    s_new = torch.zeros_like(xd)
+    s_old = torch.zeros_like(xd)
+    psiH(vp, s_old)
+    fused_grad = isinstance(grad, PsfGradient) and not as_numpy and grad.data.shape == xd.shape and grad.data.dtype == dt
     w = _dev.to_dev(l1weight, dt).contiguous()
     ws, out = _dev.scratch()
 
@@ -82,18 +110,21 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
                 vp, vn = vn, vp
             else:
                 vp.copy_(vn)
+        if k > 0:
+            s_old, s_new = s_new, s_old
         psi(xp, vn)                                                      # :135
-        dual_update_numba(vp, vn, lam, sigma=sigma, weight=w, vp_out=vp,  # :136-137
-                          group=group)
-        psiH(vp, xout)                                                   # :138
-        g = grad(host(xp))                                               # :139
-        gd = _dev.to_dev(g, dt).contiguous()
-        _lib.check(lib.pfb_pd_primal_update(code, _dev.ptr(xp), _dev.ptr(xout), _dev.ptr(gd),
-                                            float(tau),
-                                            0 if (group is not None and positivity == 2)
-                                            else int(positivity), nband, npix,
-                                            _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
-                                            _dev.stream()))              # :140-146
+        dual_update_numba(vp, vn, lam, sigma=sigma, weight=w, group=group)   # :136
+        psiH(vn, s_new)                                                  # :137-138 as 2 psiH(v) - psiH(vp)
+        if fused_grad:
+            gd, gsub = grad.conv(xp), grad.data                          # :139, `- data` inside the update
+        else:
+            gd, gsub = _dev.to_dev(grad(host(xp)), dt).contiguous(), None
+        _lib.check(lib.pfb_pd_primal_update2(code, _dev.ptr(xp), _dev.ptr(s_new), _dev.ptr(s_old), _dev.ptr(gd),
+                                             _dev.ptr(gsub), float(tau),
+                                             0 if (group is not None and positivity == 2)
+                                             else int(positivity), nband, npix,
+                                             _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
+                                             _dev.stream()))             # :140-146
         if group is not None:
             if positivity == 2:
                 bad = (xn <= 0).any(dim=0).to(torch.uint8)
