@@ -59,6 +59,11 @@ namespace pfb {
 #define PFB_STAMP_ITS 4
 #define PFB_STAMP_FIRST 2
 static __device__ unsigned long long* g_stamp_buf = nullptr;
+// experiment of the diagnostic build (tools/exp_fwd_extra_stream.py): k_row_fwd_pow2q additionally STREAMS the rows of
+// g_xtra_src (same shape as x) through registers, two 8-byte loads per even-bin sweep step, to measure how much extra
+// HBM traffic the kernel absorbs -- the question behind folding the CG update into this kernel
+static __device__ const float* g_xtra_src = nullptr;     // (not void*: hipMemcpyToSymbol's C overload would take the VALUE)
+static __device__ double* g_xtra_sink = nullptr;
 #define STAMP(KID, it, slot)                                                                              \
     do {                                                                                                  \
         const unsigned _si = (unsigned)((it) - PFB_STAMP_FIRST);                                          \
@@ -953,6 +958,22 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             __syncthreads();
         }
         STAMP(0, sit, 3);
+#if PFB_STAMP
+        if (g_xtra_src) {           // diagnostic build only: see g_xtra_src
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            constexpr int NITE_ = (P::NBE + P::BSTEP - 1) / P::BSTEP;
+            const V2* er = reinterpret_cast<const V2*>((const T*)g_xtra_src + (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch) + t;
+            T esum = 0;
+            fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G,
+                               [&](auto k) {
+                                   constexpr int K = decltype(k)::value;
+#pragma unroll
+                                   for (int j = (K * E) / NITE_; j < ((K + 1) * E) / NITE_; ++j) { const V2 e = er[TPB * j]; esum += e.x + e.y; }
+                               });
+            if (esum == T(12345.678)) g_xtra_sink[0] = (double)esum;
+        } else
+#endif
         {
             const int tid = launder((int)threadIdx.x);
             fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G);
@@ -1452,6 +1473,12 @@ int pow2_col_set_stamp(unsigned long long* buf) {
 }
 #endif
 #if PFB_POW2_REST
+int pow2_set_xtra(const void* src_, double* sink) {
+    const float* src = (const float*)src_;
+    PFB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_xtra_src), &src, sizeof(src)));
+    PFB_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_xtra_sink), &sink, sizeof(sink)));
+    return PFB_OK;
+}
 int pow2_col_set_stamp(unsigned long long* buf);
 int pow2_set_stamp(unsigned long long* buf) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) != hipSuccess) return PFB_ERR_HIP;
@@ -1972,4 +1999,6 @@ int pow2_apply(pfb_conv_plan* p, int band0, int nb, const void* x, const void* b
 #if PFB_STAMP && PFB_POW2_REST
 // diagnostic build only: buf = 3 * 1024 * PFB_STAMP_ITS * 16 device uint64 (NULL switches the stamps off)
 extern "C" int pfb_debug_set_stamps(void* buf) { return pfb::pow2_set_stamp((unsigned long long*)buf); }
+// diagnostic build only: src = an array shaped like the image cube that k_row_fwd_pow2q streams in addition (NULL: off)
+extern "C" int pfb_debug_set_extra_stream(const void* src, double* sink) { return pfb::pow2_set_xtra(src, sink); }
 #endif
