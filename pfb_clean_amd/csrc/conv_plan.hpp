@@ -20,6 +20,10 @@ struct pfb_conv_plan {
     int nband, dtype;
     int VB, nvb;               // column blocking, number of column blocks
     int fast;                  // 1: pow2 register-resident kernels are used
+    int long_lines;            // 1: a line does not fit the LDS and the fast path cannot hold the grid: every transform
+                               //    runs as multi-launch global-memory passes (fft_long.hpp) -- coverage, not speed
+    void* long_ws;             // its workspace (grown on demand, freed with the plan)
+    size_t long_ws_bytes;
     pfb::FftFactors frow;      // length M  (row transform on packed reals)
     pfb::FftFactors fcol;      // length P
     void* twP;

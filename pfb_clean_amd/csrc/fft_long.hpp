@@ -241,4 +241,164 @@ static int long_cols(cplx<T>* data, const cplx<T>* twP, int nband, int P, int M1
     return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The convolution itself on long lines (coverage path of pfb_psfconv_apply when a line fits neither the LDS nor the
+// fast path: e.g. nx > 8192, or fp64 rows of more than 8192 pixels).  Same three stages and the same T / psf_l layouts
+// as the line-in-LDS kernels of fftconv.hip (VB = 1: T[band][v][i], psf_l[band][v][u]), every FFT as global passes.
+
+// z[bl][i][n] = (x[2n], x[2n+1]) [* beam], zero beyond ny
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_pack_x(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ z, int nx, int ny, int M) {
+    const size_t r = (size_t)blockIdx.z * nx + blockIdx.y;
+    const T* xr = x + r * ny;
+    const T* br = beam ? beam + r * ny : nullptr;
+    cplx<T>* zr = z + r * M;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < M; n += gridDim.x * blockDim.x) {
+        const int j0 = 2 * n, j1 = 2 * n + 1;
+        T a = 0, b = 0;
+        if (j0 < ny) a = br ? xr[j0] * br[j0] : xr[j0];
+        if (j1 < ny) b = br ? xr[j1] * br[j1] : xr[j1];
+        zr[n] = cplx<T>(a, b);
+    }
+}
+
+// T[band][v][i] = X[v] of row i (Hermitian unpacking of the packed transform), v = 0..M
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_rows_to_T(const cplx<T>* __restrict__ z, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
+                 int nx, int M, size_t T_band, int band0) {
+    const int i = blockIdx.y, bl = blockIdx.z;
+    const cplx<T>* zr = z + ((size_t)bl * nx + i) * M;
+    cplx<T>* Tb = Tw + (size_t)(band0 + bl) * T_band;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v <= M; v += gridDim.x * blockDim.x) {
+        const cplx<T> zv = zr[v == M ? 0 : v];
+        const cplx<T> zm = conj(zr[v == 0 ? 0 : M - v]);
+        Tb[(size_t)v * nx + i] = T(0.5) * ((zv + zm) + mul_mi(twQ[v] * (zv - zm)));
+    }
+}
+
+// C[v][u] = u < nx ? T[band][v][u] : 0     (one zero-padded column per line, contiguous)
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_col_load(const cplx<T>* __restrict__ Tb, cplx<T>* __restrict__ Cw, int nx, int P) {
+    const size_t v = blockIdx.y;
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < P; u += gridDim.x * blockDim.x)
+        Cw[v * P + u] = u < nx ? Tb[v * nx + u] : cplx<T>(0, 0);
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_col_mul(cplx<T>* __restrict__ Cw, const cplx<T>* __restrict__ psf_b, size_t n) {
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t)gridDim.x * blockDim.x)
+        Cw[k] = Cw[k] * psf_b[k];
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_col_store(const cplx<T>* __restrict__ Cw, cplx<T>* __restrict__ Tb, int nx, int P) {
+    const size_t v = blockIdx.y;
+    for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < nx; u += gridDim.x * blockDim.x)
+        Tb[v * nx + u] = Cw[v * P + u];
+}
+
+// z[bl][i][v] = (Y[v] + conj Y[M-v]) + i conj(w_Q^v) (Y[v] - conj Y[M-v]),  Y[v] = T[band][v][i]
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_T_to_rows(const cplx<T>* __restrict__ Tw, cplx<T>* __restrict__ z, const cplx<T>* __restrict__ twQ,
+                 int nx, int M, size_t T_band, int band0) {
+    const int i = blockIdx.y, bl = blockIdx.z;
+    const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * T_band;
+    cplx<T>* zr = z + ((size_t)bl * nx + i) * M;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < M; v += gridDim.x * blockDim.x) {
+        cplx<T> yv = Tb[(size_t)v * nx + i], ym = Tb[(size_t)(M - v) * nx + i];
+        if (v == 0) { yv.y = 0; ym.y = 0; }
+        ym = conj(ym);
+        zr[v] = (yv + ym) + mul_i(mulc(yv - ym, twQ[v]));
+    }
+}
+
+// out = z * scale [* beam] + sigmainv x, one workgroup per row; fused <dot_with,out>, <dot_with2,out>, <out,out>
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_long_epilogue(const cplx<T>* __restrict__ z, const T* __restrict__ x, const T* __restrict__ beam,
+                const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
+                double* __restrict__ partials, int nx, int ny, int M, T scale, T sigmainv) {
+    __shared__ double red[3 * 4];
+    const int i = blockIdx.x, bl = blockIdx.y;
+    const size_t rowoff = ((size_t)bl * nx + i) * ny;
+    const cplx<T>* zr = z + ((size_t)bl * nx + i) * M;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int j = threadIdx.x; j < ny; j += blockDim.x) {
+        const cplx<T> zz = zr[j >> 1];
+        T val = ((j & 1) ? zz.y : zz.x) * scale;
+        if (beam) val *= beam[rowoff + j];
+        val += sigmainv * x[rowoff + j];
+        out[rowoff + j] = val;
+        if (dot_with) {
+            acc[0] += (double)dot_with[rowoff + j] * (double)val;
+            if (dot_with2) acc[1] += (double)dot_with2[rowoff + j] * (double)val;
+            acc[2] += (double)val * (double)val;
+        }
+    }
+    if (dot_with) {
+        block_sum<3>(acc, red);
+        if (threadIdx.x == 0) {
+            const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * nx + i;
+            partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2];
+        }
+    }
+}
+
+static inline dim3 long_grid(int n, int y, int zdim) {
+    int gx = (n + 255) / 256;
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)y, (unsigned)zdim);
+}
+
+// workspace bytes of apply_long for nb bands: row buffers 2 x nb x nx x M, column buffers 2 x (M+1) x P (one band at a time)
+template <typename T>
+static size_t long_apply_ws_bytes(int nb, int nx, int M, int P) {
+    const size_t rows = 2 * (size_t)nb * nx * M, cols = 2 * (size_t)(M + 1) * P;
+    return sizeof(cplx<T>) * (rows > cols ? rows : cols);
+}
+
+template <typename T>
+static int apply_long(cplx<T>* ws, cplx<T>* Tw, const cplx<T>* psf_l, double* partials, const cplx<T>* twP,
+                      const cplx<T>* twQ, const FftFactors& frow, const FftFactors& fcol, int nx, int ny, int P, int M,
+                      size_t T_band, size_t psf_band, int band0, int nb, const T* x, const T* beam, double scale,
+                      double sigmainv, T* out, const T* dot_with, const T* dot_with2, hipStream_t st) {
+    const size_t nrow = (size_t)nb * nx * M, ncol = (size_t)(M + 1) * P;
+    cplx<T>* z = ws;
+    cplx<T>* zw = ws + nrow;
+    // 1. rows forward
+    hipLaunchKernelGGL((k_long_pack_x<T>), long_grid(M, nx, nb), dim3(256), 0, st, x, beam, z, nx, ny, M);
+    int rc = long_fft<T, false>(z, zw, nrow, frow, twQ, 2, (size_t)nb * nx, 1, (size_t)M, st);
+    if (rc != PFB_OK) return rc;
+    hipLaunchKernelGGL((k_long_rows_to_T<T>), long_grid(M + 1, nx, nb), dim3(256), 0, st, (const cplx<T>*)z, Tw, twQ, nx, M,
+                       T_band, band0);
+    // 2. columns, band by band: zero-pad, forward, multiply by psfhat, inverse, keep the first nx samples
+    cplx<T>* C1 = ws;
+    cplx<T>* C2 = ws + ncol;
+    for (int bl = 0; bl < nb && rc == PFB_OK; ++bl) {
+        cplx<T>* Tb = Tw + (size_t)(band0 + bl) * T_band;
+        hipLaunchKernelGGL((k_long_col_load<T>), long_grid(P, M + 1, 1), dim3(256), 0, st, (const cplx<T>*)Tb, C1, nx, P);
+        rc = long_fft<T, false>(C1, C2, ncol, fcol, twP, 1, (size_t)(M + 1), 1, (size_t)P, st);
+        if (rc != PFB_OK) break;
+        hipLaunchKernelGGL((k_long_col_mul<T>), dim3(4096), dim3(256), 0, st, C1, psf_l + (size_t)(band0 + bl) * psf_band, ncol);
+        rc = long_fft<T, true>(C1, C2, ncol, fcol, twP, 1, (size_t)(M + 1), 1, (size_t)P, st);
+        if (rc != PFB_OK) break;
+        hipLaunchKernelGGL((k_long_col_store<T>), long_grid(nx, M + 1, 1), dim3(256), 0, st, (const cplx<T>*)C1, Tb, nx, P);
+    }
+    if (rc != PFB_OK) return rc;
+    // 3. rows inverse + epilogue
+    hipLaunchKernelGGL((k_long_T_to_rows<T>), long_grid(M, nx, nb), dim3(256), 0, st, (const cplx<T>*)Tw, z, twQ, nx, M,
+                       T_band, band0);
+    rc = long_fft<T, true>(z, zw, nrow, frow, twQ, 2, (size_t)nb * nx, 1, (size_t)M, st);
+    if (rc != PFB_OK) return rc;
+    hipLaunchKernelGGL((k_long_epilogue<T>), dim3(nx, nb), dim3(256), 0, st, (const cplx<T>*)z, x, beam, dot_with, dot_with2,
+                       out, partials, nx, ny, M, (T)scale, (T)sigmainv);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
 }  // namespace pfb

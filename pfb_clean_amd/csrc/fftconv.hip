@@ -492,13 +492,10 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
         return PFB_ERR_UNSUPPORTED;
     }
     if (!p->fast) {
+        // a line that does not fit the two LDS buffers of the line-per-workgroup kernels: every transform of this plan
+        // runs as global-memory passes instead (fft_long.hpp) -- slow, but no grid is refused for its size
         const size_t lds_need = 128 + 2 * csz * (size_t)(p->P > p->M ? p->P : p->M);
-        if (lds_need > 160 * 1024) {
-            free(p);
-            set_error("plan_create: generic path needs %zu B of LDS (> 160 KB) for grid (%d,%d); "
-                      "use a power-of-two grid with nx_psf = 2 nx", lds_need, nx_psf, ny_psf);
-            return PFB_ERR_UNSUPPORTED;
-        }
+        if (lds_need > 160 * 1024) p->long_lines = 1;
     }
     int rc = (dtype == PFB_F32) ? upload_twiddles<float>(p->P, &p->twP) : upload_twiddles<double>(p->P, &p->twP);
     if (rc == PFB_OK)
@@ -530,6 +527,7 @@ int pfb_psfconv_plan_destroy(pfb_conv_plan* p) {
     if (p->psf_l) (void)hipFree(p->psf_l);
     if (p->T) (void)hipFree(p->T);
     if (p->partials) (void)hipFree(p->partials);
+    if (p->long_ws) (void)hipFree(p->long_ws);
     pow2_release(p);
     if (p->prof_ev) {
         for (int k = 0; k < 4 * PROF_MAX; ++k) (void)hipEventDestroy(p->prof_ev[k]);
@@ -664,7 +662,34 @@ static int apply_common(pfb_conv_plan* p, int band0, int nb, const void* x, cons
     p->last_npartials = p->partials_per_band * nb;        // the persistent row-inverse kernel lowers it
     if (p->fast)
         rc = pow2_apply(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
-    else if (p->dtype == PFB_F32)
+    else if (p->long_lines) {
+        const size_t need = p->dtype == PFB_F32 ? long_apply_ws_bytes<float>(nb, p->nx, p->M, p->P)
+                                                : long_apply_ws_bytes<double>(nb, p->nx, p->M, p->P);
+        if (need > p->long_ws_bytes) {
+            PFB_HIP_CHECK(hipStreamSynchronize(st));
+            if (p->long_ws) (void)hipFree(p->long_ws);
+            p->long_ws = nullptr; p->long_ws_bytes = 0;
+            if (hipMalloc(&p->long_ws, need) != hipSuccess) {
+                set_error("apply: workspace allocation of %zu B for the long-line path failed", need);
+                return PFB_ERR_ALLOC;
+            }
+            p->long_ws_bytes = need;
+        }
+        prof_mark(p, st, 0); prof_mark(p, st, 1); prof_mark(p, st, 2);
+        if (p->dtype == PFB_F32)
+            rc = apply_long<float>((cplx<float>*)p->long_ws, (cplx<float>*)p->T, (const cplx<float>*)p->psf_l, p->partials,
+                                   (const cplx<float>*)p->twP, (const cplx<float>*)p->twQ, p->frow, p->fcol, p->nx, p->ny,
+                                   p->P, p->M, p->T_elems_per_band, p->psf_elems_per_band, band0, nb, (const float*)x,
+                                   (const float*)beam, scale, sigmainv, (float*)out, (const float*)dot_with,
+                                   (const float*)dot_with2, st);
+        else
+            rc = apply_long<double>((cplx<double>*)p->long_ws, (cplx<double>*)p->T, (const cplx<double>*)p->psf_l,
+                                    p->partials, (const cplx<double>*)p->twP, (const cplx<double>*)p->twQ, p->frow, p->fcol,
+                                    p->nx, p->ny, p->P, p->M, p->T_elems_per_band, p->psf_elems_per_band, band0, nb,
+                                    (const double*)x, (const double*)beam, scale, sigmainv, (double*)out,
+                                    (const double*)dot_with, (const double*)dot_with2, st);
+        prof_mark(p, st, 3);
+    } else if (p->dtype == PFB_F32)
         rc = apply_generic<float>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);
     else
         rc = apply_generic<double>(p, band0, nb, x, beam, scale, sigmainv, out, dot_with, dot_with2, st);

@@ -93,6 +93,9 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
     # images): embedded in the power-of-two fast path, the re-gridding runs its long lines as global-memory passes
     (6000, 96, 12000, 192), (7200, 64, 14400, 128), (5040, 64, 10080, 128), (3000, 64, 6000, 128),
     (8000, 64, 16000, 128), (6000, 96, 9000, 144), (96, 7200, 192, 14400),
+    # beyond the fast path as well (nx > 8192; fp64 rows of more than 8192 pixels): the long-line coverage path,
+    # every transform as global-memory passes
+    (9000, 32, 18000, 64), (10000, 48, 12000, 96), (64, 10000, 128, 20000),
 ]
 
 
@@ -100,8 +103,6 @@ SIZES = [  # nx, ny, nx_psf, ny_psf : pow2 2x (fast path), mixed radix, aliasing
 @pmp('size', SIZES)
 def test_conv_vs_oracle_sizes(amd, size, rdt):
     nx, ny, P, Q = size
-    if ny > 8192 and rdt == np.float64:
-        pytest.skip("fp64 rows of ny > 8192 pixels do not fit the LDS (documented limit: DESIGN 4.1)")
     rng = np.random.default_rng(nx * 1000 + ny)
     nb = 2
     psf = rng.standard_normal((nb, P, Q))
@@ -701,3 +702,26 @@ def test_fp32_predictive_backtracking_matches_reference_loop(amd, n, nb):
     xo = osv.pcg(Ao, b64, None, M=lambda w: w / sigmainv, tol=0.0, maxit=25, minit=25, trace=tr)
     assert relerr(xp_.cpu().numpy(), xo) < 5 * TOL_PCG[np.float32]
     assert relerr(xe_.cpu().numpy(), xo) < 5 * TOL_PCG[np.float32]
+
+
+def test_long_line_coverage_path_runs_the_fused_pcg(amd):
+    """A grid neither the LDS kernels nor the fast path can hold (nx = 9000 > 8192, nx_psf = 18000): the plan takes the
+    long-line coverage path (every FFT as global-memory passes) and the fused PCG on it -- fused dots out of its
+    epilogue included -- follows the oracle's iterates."""
+    rng = np.random.default_rng(9)
+    nb, nx, ny = 1, 9000, 24
+    P, Q = 2 * nx, 2 * ny
+    psf = np.zeros((nb, P, Q))
+    psf[:, P // 2 - 3:P // 2 + 4, Q // 2 - 3:Q // 2 + 4] = rng.random((nb, 7, 7))
+    psf[:, P // 2, Q // 2] += 30.0
+    psfhat = ofc.psfhat_from_psf(psf)
+    b = rng.standard_normal((nb, nx, ny))
+    sig = 0.5
+    A = amd.hessian.HessianPsf(torch.from_numpy(psfhat).cuda(), nx, ny, Q, sigmainv=sig)
+    assert not A.plan.fast_path and A.plan.embed is None
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, b.shape, np.float64)
+    Ao = lambda v: ofc.hessian_psf_cube(xpad, xhat, xout, None, psfhat, Q, v, sigmainv=sig)
+    assert relerr(A(torch.from_numpy(b).cuda()).cpu().numpy(), Ao(b)) < 1e-12
+    x, _, res = amd.pcg.pcg_fused(A, torch.from_numpy(b).cuda(), None, mdiv=sig, tol=0.0, maxit=6, minit=6)
+    xo = osv.pcg(Ao, b, None, M=lambda v: v / sig, tol=0.0, maxit=6, minit=6)
+    assert res.iters == 6 and relerr(x.cpu().numpy(), xo) < 1e-9
