@@ -549,7 +549,10 @@ static int launch_update_dir(size_t n, const T* x, const T* r, T* p, const T* Ap
     if (can_vec<T>(n, PL{x, r, p, Ap, xn, rn})) {
         const size_t nvec = n / V;
         const int G = stream_grid(nvec);
-        static const bool xnt = [] { const char* e = getenv("PFB_UPD_XNT"); return !e || atoi(e); }();
+        // x non-temporal only when the vectors are far beyond the caches anyway (>= 32 MB each): small problems live in
+        // L2 / the Infinity Cache between iterations and nt would send x to HBM (1024^2: 0.060 -> 0.066 ms per iteration)
+        static const bool xnt_on = [] { const char* e = getenv("PFB_UPD_XNT"); return !e || atoi(e); }();
+        const bool xnt = xnt_on && n * sizeof(T) >= ((size_t)32 << 20);
         if (unroll == 2 && xnt)
             hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2, true>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
         else if (unroll == 2)

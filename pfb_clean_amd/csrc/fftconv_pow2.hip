@@ -1776,7 +1776,10 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
         const size_t tab = sizeof(cplx<T>) * (size_t)((F::PTWC + 1) & ~1);
         const bool db = db_on && wg_per_cu == 1 && 2 * lds + tab <= (size_t)160 * 1024;
         // psf read with non-temporal loads (see loadb_nt); PFB_PSF_NT=0: A/B
-        static const bool psf_nt = [] { const char* e = getenv("PFB_PSF_NT"); return !e || atoi(e); }();
+        // ... only when this launch's share of the PSF spectrum is itself of the Infinity Cache's size or larger: a
+        // smaller one is RE-READ from that cache by the next apply and must stay allocatable
+        static const bool psf_nt_on = [] { const char* e = getenv("PFB_PSF_NT"); return !e || atoi(e); }();
+        const bool psf_nt = psf_nt_on && sizeof(cplx<T>) * p->psf_elems_per_band * (size_t)nb >= ((size_t)200 << 20);
 #define PFB_COLP(DBV, SPV)                                                                                     \
         if (SPV && psf_nt)                                                                                     \
         hipLaunchKernelGGL((k_col_pow2p<T, H, E, DBV, SPV, SPV>), dim3(grid), dim3(GC * F::TPB), (DBV ? 2 : 1) * lds + tab, st, \
