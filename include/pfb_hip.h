@@ -74,7 +74,12 @@ typedef struct pfb_conv_plan pfb_conv_plan;
 
 /* nx,ny: image; nx_psf,ny_psf(=lastsize): padded PSF grid, ny_psf even,
  * nx <= nx_psf, ny <= ny_psf; every 1-D length must factor into {2,3,5,7,11,13}.
- * nband: leading (imaging band) axis of the cubes this plan serves. */
+ * nband: leading (imaging band) axis of the cubes this plan serves.
+ * Three kernel families behind one plan, chosen here: power-of-two images with nx_psf = 2 nx, ny_psf = 2 ny
+ * (64 <= nx <= 8192, 128 <= ny <= 16384 fp32 / 8192 fp64) take the register-FFT fast path; other grids the
+ * line-in-LDS coverage kernels while a line fits (<= 10240 complex64 / 5120 complex128), and multi-launch
+ * global-memory passes beyond that -- no grid is refused for its size (the host layer embeds arbitrary sizes in the
+ * fast path through pfb_psfhat_regrid whenever that is possible: see pfb_clean_amd/operators/psf.py). */
 int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband,
                             int dtype, pfb_conv_plan** plan);
 int pfb_psfconv_plan_destroy(pfb_conv_plan* plan);

@@ -287,10 +287,10 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
     }
-    // 8192-point fp64 columns: one 512-thread workgroup per CU (its exchange buffer fills the LDS; the persistent
-    // kernel's twiddle table no longer fits) and 256 VGPRs per thread: psf_e is requested BEFORE the first transform and
-    // psf_o before the second, so that two of the three HBM latencies of a block hide behind a transform
-    // (2.97 -> see DESIGN 5 ms per 2 bands).  Elsewhere (128-VGPR cap) the loads stay behind the transforms.
+    // PREQ (OFF): request psf_e BEFORE the first transform and psf_o before the second, so that two of the three HBM
+    // latencies of a block hide behind a transform.  Meant for the 8192-point fp64 columns (one 512-thread workgroup per
+    // CU, 256 VGPRs per thread; the persistent kernel does not fit there), but vv + aw + q are 192 registers before the
+    // radix-16 butterfly's own 64: 84 -> 556 bytes of scratch per lane.  Kept for the record, not compiled in.
     constexpr bool PREQ = false && sizeof(T) == 8 && H >= 8192;
     Blk<T, NVB> q[PREQ ? E : 1];
     if constexpr (PREQ) {
