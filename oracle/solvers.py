@@ -393,3 +393,31 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
         xp[...] = x[...]
         vp[...] = v[...]
     return x, v
+
+
+def primal_dual(x, v, lam, psi, psiH, L, prox, grad, nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000, minit=10,
+                positivity=1, report_freq=10, gamma=1.0, verbosity=1):
+    """primal_dual.py:12-87 -- the un-optimised functional form: psiH(x) RETURNS the analysis coefficients, psi(v)
+    the synthesised image, prox(v, sigma) is a callable; stopping rule `(eps > tol or k < minit) and k < maxit`,
+    eps = |x - xp| / |x| (no 1e-12 guard here).  Where the reference drops into pdb (NaN / inf eps) we carry on."""
+    xp = x.copy()
+    vp = v.copy()
+    if sigma is None:
+        sigma = L / (2.0 * gamma) / nu
+    tau = 0.9 / (L / (2.0 * gamma) + sigma * nu ** 2)
+    eps = 1.0
+    k = 0
+    while (eps > tol or k < minit) and k < maxit:
+        vtilde = v + sigma * psiH(xp)
+        v = vtilde - sigma * prox(vtilde / sigma, lam / sigma)
+        x = xp - tau * (psi(2 * v - vp) + grad(xp))
+        if positivity == 1:
+            x[x < 0.0] = 0.0
+        elif positivity == 2:
+            msk = np.any(x <= 0, axis=0)
+            x[:, msk] = 0.0
+        eps = np.linalg.norm(x - xp) / np.linalg.norm(x)
+        xp[...] = x[...]
+        vp[...] = v[...]
+        k += 1
+    return x, v

@@ -170,3 +170,76 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     if vn is not v:
         v.copy_(vn)
     return x, v
+
+
+def primal_dual(x, v, lam, psi, psiH, L, prox, grad, nu=1.0, sigma=None, mask=None, tol=1e-5, maxit=1000,
+                minit=10, positivity=1, report_freq=10, gamma=1.0, verbosity=1):
+    """pfb/opt/primal_dual.py:12-87 -- the un-optimised, functional form of the same iteration (the one
+    workers/fwdbwd.py:367 names): `psiH(x)` RETURNS the analysis coefficients, `psi(v)` RETURNS the synthesised image,
+    `prox(v, sigma)` is any callable (prox_21m of this package keeps it on the device), `grad(x)` the smooth term.
+    Same positional order as the reference (note psi / psiH swapped w.r.t. primal_dual_optimised), stopping rule
+    `(eps > tol or k < minit) and k < maxit`, eps = |x - xp| / |x| (no 1e-12 guard in this variant).
+    The combinations between the operator calls run in the library's vector kernels (pfb_axpby) and the primal update
+    with positivity and the two norms in pfb_pd_primal_update; the callables see GPU tensors when x is a tensor, numpy
+    arrays when x is numpy (drop-in: every call then crosses PCIe).  Returns NEW x, v like the reference."""
+    lib = _lib.load()
+    as_numpy = _dev.is_numpy(x)
+    xd = _dev.to_dev(x).contiguous()
+    dt = xd.dtype
+    code = _dev.code(dt)
+    vd = _dev.to_dev(v, dt).contiguous()
+    nband, npix = xd.shape[0], xd[0].numel()
+    ws, out = _dev.scratch()
+    if sigma is None:
+        sigma = L / (2.0 * gamma) / nu
+    tau = 0.9 / (L / (2.0 * gamma) + sigma * nu ** 2)
+
+    def host(t):
+        return t.cpu().numpy() if as_numpy else t
+
+    def dev(a, private=False):                    # result of a caller's operator -> contiguous device tensor
+        t = _dev.to_dev(a, dt).contiguous()       # private: we write into it -- never into a buffer the caller may own
+        return t.clone() if (private and isinstance(a, torch.Tensor)) or t.data_ptr() in keep else t
+
+    def axpby(a, u, b, w):                        # w = a*u + b*w
+        _lib.check(lib.pfb_axpby(code, float(a), _dev.ptr(u), float(b), _dev.ptr(w), w.numel(), _dev.stream()))
+
+    xp = xd.clone()
+    vp = vd.clone()
+    vcur = vd.clone()
+    xnew = torch.empty_like(xd)
+    keep = set()
+    eps, k = 1.0, 0
+    while (eps > tol or k < minit) and k < maxit:
+        keep = {xp.data_ptr(), vp.data_ptr(), vcur.data_ptr()}
+        vt = dev(psiH(host(xp)), private=True)                    # psiH(xp)
+        axpby(1.0, vcur, sigma, vt)                               # vtilde = v + sigma psiH(xp)            :49
+        arg = vt.clone()
+        axpby(0.0, vt, 1.0 / sigma, arg)                          # vtilde / sigma
+        pr = dev(prox(host(arg), lam / sigma))
+        axpby(-sigma, pr, 1.0, vt)                                # v = vtilde - sigma prox(vtilde/sigma)  :52
+        vcur, vt = vt, vcur
+        axpby(2.0, vcur, -1.0, vp)                                # vp <- 2 v - vp (vp is re-set below)    :55
+        so = dev(psi(host(vp)))
+        g = dev(grad(host(xp)))
+        _lib.check(lib.pfb_pd_primal_update(code, _dev.ptr(xp), _dev.ptr(so), _dev.ptr(g), float(tau),
+                                            int(positivity), nband, npix, _dev.ptr(xnew), _dev.ptr(out),
+                                            _dev.ptr(ws), _dev.stream()))                         # :55-60
+        num, den, _ = out[:3].tolist()
+        eps = math.sqrt(num) / math.sqrt(den) if den > 0 else float('nan')                        # :63
+        xp.copy_(xnew)
+        vp.copy_(vcur)
+        if math.isnan(eps) or math.isinf(eps):
+            print("primal_dual: non-finite eps (the reference stops in pdb here)", file=sys.stderr)
+            break
+        if not k % report_freq and verbosity > 1:
+            print(f"At iteration {k} eps = {eps:.3e}", file=sys.stderr)
+        k += 1
+    if verbosity:
+        if k == maxit:
+            print(f"Max iters reached. eps = {eps:.3e}", file=sys.stderr)
+        else:
+            print(f"Success, converged after {k} iterations", file=sys.stderr)
+    if as_numpy:
+        return xp.cpu().numpy(), vcur.cpu().numpy()
+    return xp.clone(), vcur

@@ -28,7 +28,7 @@ from pfb.operators.psf import psf_convolve_slice, psf_convolve_cube  # noqa: E40
 from pfb.operators.hessian import _hessian_psf_slice, hessian_psf_cube, hessian_psf_slice  # noqa: E402
 from pfb.opt.pcg import pcg, _pcg_psf_impl, pcg_dist, cg_dct, cg  # noqa: E402
 from pfb.opt.power_method import power_method  # noqa: E402
-from pfb.opt.primal_dual import primal_dual_optimised  # noqa: E402
+from pfb.opt.primal_dual import primal_dual_optimised, primal_dual  # noqa: E402
 from pfb.operators.psi import Psi  # noqa: E402
 from pfb.prox.prox_21m import (prox_21m, prox_21m_numba, dual_update,  # noqa: E402
                                dual_update_numba)
@@ -286,6 +286,56 @@ def gen_pd():
     print('pd.npz', len(out))
 
 
+def gen_pdplain():
+    """primal_dual (primal_dual.py:12-87), the un-optimised functional form: psiH / psi RETURN arrays, prox is a
+    callable; operators built from the reference's own Psi and prox_21m."""
+    out = {}
+    rng = np.random.default_rng(461)
+    nb, nx, ny, P, Q = 2, 32, 24, 64, 48
+    bases = ['self', 'db1', 'db3']
+    nlevel = 2
+    psfhat = psd_psfhat(rng, nb, P, Q)
+    xpad, xhat, xout = scratch(psfhat, Q, (nb, nx, ny))
+    conv = partial(psf_convolve_cube, xpad, xhat, xout, psfhat, Q)
+    truth = np.zeros((nb, nx, ny))
+    truth[:, 10, 12] = 1.0
+    truth[:, 20, 8] = 0.5
+    truth[:, 15:18, 16:19] = 0.2
+    data = conv(truth).copy() + 1e-4 * rng.standard_normal(truth.shape)
+    psiop = Psi(nb, nx, ny, bases, nlevel, 1)
+    nbasis = len(bases)
+    l1weight = 0.5 + rng.random((nbasis, psiop.Nymax, psiop.Nxmax))
+
+    def psiH(x):                                  # analysis: image -> coefficients (new array)
+        a = np.zeros((nb, nbasis, psiop.Nymax, psiop.Nxmax))
+        psiop.dot(x, a)
+        return a
+
+    def psi(a):                                   # synthesis: coefficients -> image (new array)
+        x = np.zeros((nb, nx, ny))
+        psiop.hdot(a, x)
+        return x
+
+    def prox(v, sig):
+        return prox_21m(v, sig, weight=l1weight)
+
+    def grad(x):
+        return conv(x) - data
+    hessnorm = 1.05 * power_method(conv, (nb, nx, ny), b0=rng.standard_normal((nb, nx, ny)),
+                                   tol=1e-4, maxit=100, verbosity=0)[0]
+    lam = 2e-3
+    out.update(psfhat=psfhat, data=data, hessnorm=hessnorm, lam=lam, bases=np.array(bases), nlevel=nlevel, Q=Q,
+               l1weight=l1weight)
+    for tag, pos, kw in (('pos1', 1, dict(tol=0.0, maxit=8, minit=2)), ('pos0', 0, dict(tol=0.0, maxit=5, minit=1)),
+                         ('pos2', 2, dict(tol=0.0, maxit=6, minit=1)), ('tol', 1, dict(tol=5e-2, maxit=60, minit=3))):
+        x, v = primal_dual(np.zeros((nb, nx, ny)), np.zeros((nb, nbasis, psiop.Nymax, psiop.Nxmax)), lam, psi, psiH,
+                           hessnorm, prox, grad, nu=nbasis, positivity=pos, report_freq=1000, gamma=1.0, verbosity=0, **kw)
+        out[f'{tag}_x'] = x.copy()
+        out[f'{tag}_v'] = v.copy()
+    np.savez_compressed(os.path.join(HERE, 'pdplain.npz'), **out)
+    print('pdplain.npz', len(out))
+
+
 class _Var:
     """Stand-in for an xarray variable: .values / .dtype / .shape is all hessian.py:161-221 touches."""
     def __init__(self, a):
@@ -537,6 +587,6 @@ def gen_cg():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'dist', 'dct', 'clark', 'misc', 'cg']
+    which = sys.argv[1:] or ['conv', 'pcg', 'psi', 'prox', 'pd', 'pdplain', 'dist', 'dct', 'clark', 'misc', 'cg']
     for w in which:
         globals()['gen_' + w]()

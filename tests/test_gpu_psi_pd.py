@@ -371,3 +371,46 @@ def test_long_filters_against_oracle(amd, case, rdt):
     tol = 1e-12 if rdt == np.float64 else 2e-5
     assert np.abs(a - a_ref).max() < tol * np.abs(a_ref).max()
     assert np.abs(xo - xo_ref).max() < tol * np.abs(xo_ref).max()
+
+
+@pytest.mark.parametrize('kind', ['numpy', 'tensor'])
+def test_primal_dual_unoptimised_golden(amd, golden, kind):
+    """primal_dual (primal_dual.py:12-87, the functional form workers/fwdbwd.py:367 names) against the reference's own
+    trajectories (tests/golden/pdplain.npz): operators built from this package's Psi / prox_21m / psf_convolve_cube,
+    numpy in -> numpy out and tensors staying on the device."""
+    from pfb_clean_amd.opt.primal_dual import primal_dual
+    from pfb_clean_amd.prox.prox_21m import prox_21m
+    g = golden('pdplain')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx, ny = P // 2, Q // 2
+    bases = [str(b) for b in g['bases']]
+    ps = amd.Psi(nb, nx, ny, bases, int(g['nlevel']), 1)
+    nbasis = len(bases)
+    dev = torch.device('cuda')
+    t = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)) if kind == 'tensor' else (lambda a: a)
+    data, w, ph = t(g['data']), t(g['l1weight']), t(psfhat)
+    zeros = (lambda *s: torch.zeros(s, dtype=torch.float64, device=dev)) if kind == 'tensor' else (lambda *s: np.zeros(s))
+
+    def psiH(x):
+        a = zeros(nb, nbasis, ps.Nymax, ps.Nxmax)
+        ps.dot(x, a)
+        return a
+
+    def psi(a):
+        x = zeros(nb, nx, ny)
+        ps.hdot(a, x)
+        return x
+
+    def grad(x):
+        return amd.psf.psf_convolve_cube(None, None, None, ph, Q, x) - data
+    for tag, pos, kw in (('pos1', 1, dict(tol=0.0, maxit=8, minit=2)), ('pos0', 0, dict(tol=0.0, maxit=5, minit=1)),
+                         ('pos2', 2, dict(tol=0.0, maxit=6, minit=1)), ('tol', 1, dict(tol=5e-2, maxit=60, minit=3))):
+        x0, v0 = zeros(nb, nx, ny), zeros(nb, nbasis, ps.Nymax, ps.Nxmax)
+        x, v = primal_dual(x0, v0, float(g['lam']), psi, psiH, float(g['hessnorm']),
+                           lambda u, s: prox_21m(u, s, weight=w), grad, nu=nbasis, positivity=pos, verbosity=0, **kw)
+        xh = x.cpu().numpy() if kind == 'tensor' else x
+        vh = v.cpu().numpy() if kind == 'tensor' else v
+        assert (kind == 'tensor') == isinstance(x, torch.Tensor)
+        assert maxerr(xh, g[f'{tag}_x']) < 1e-9 * np.abs(g[f'{tag}_x']).max(), tag
+        assert maxerr(vh, g[f'{tag}_v']) < 1e-9 * np.abs(g[f'{tag}_v']).max(), tag

@@ -527,3 +527,36 @@ def test_plain_cg_pinned(golden):
         assert_allclose(sv.cg(A, b, None, tol=0.0, maxit=k, verbosity=0), g[f'k{k}'], rtol=1e-10, atol=1e-12)
     assert_allclose(sv.cg(A, b, None, tol=1e-6, maxit=500, verbosity=0), g['tol'], rtol=1e-7, atol=1e-9)
     assert_allclose(sv.cg(A, b, g['x0'], tol=0.0, maxit=5, verbosity=0), g['warm_k5'], rtol=1e-10, atol=1e-12)
+
+
+def test_primal_dual_unoptimised_golden(golden):
+    """oracle/solvers.primal_dual (primal_dual.py:12-87, the functional form) against trajectories the reference's
+    own function produced (tests/golden/pdplain.npz): positivity 0 / 1 / 2 with minit forcing, and a live tolerance."""
+    from oracle import solvers as osv, fftconv as ofc, wavelets as owv, prox as opx
+    g = golden('pdplain')
+    psfhat, Q = g['psfhat'], int(g['Q'])
+    nb, P, _ = psfhat.shape
+    nx, ny = P // 2, Q // 2
+    bases = [str(b) for b in g['bases']]
+    ps = owv.Psi(nb, nx, ny, bases, int(g['nlevel']))
+    nbasis = len(bases)
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, (nb, nx, ny), np.float64)
+    data, w = g['data'], g['l1weight']
+
+    def psiH(x):
+        a = np.zeros((nb, nbasis, ps.Nymax, ps.Nxmax))
+        ps.dot(x, a)
+        return a
+
+    def psi(a):
+        x = np.zeros((nb, nx, ny))
+        ps.hdot(a, x)
+        return x
+    for tag, pos, kw in (('pos1', 1, dict(tol=0.0, maxit=8, minit=2)), ('pos0', 0, dict(tol=0.0, maxit=5, minit=1)),
+                         ('pos2', 2, dict(tol=0.0, maxit=6, minit=1)), ('tol', 1, dict(tol=5e-2, maxit=60, minit=3))):
+        x, v = osv.primal_dual(np.zeros((nb, nx, ny)), np.zeros((nb, nbasis, ps.Nymax, ps.Nxmax)), float(g['lam']), psi,
+                               psiH, float(g['hessnorm']), lambda u, s: opx.prox_21m(u, s, weight=w),
+                               lambda u: ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, u) - data, nu=nbasis,
+                               positivity=pos, verbosity=0, **kw)
+        assert np.abs(x - g[f'{tag}_x']).max() <= 1e-13 * np.abs(g[f'{tag}_x']).max(), tag
+        assert np.abs(v - g[f'{tag}_v']).max() <= 1e-13 * np.abs(g[f'{tag}_v']).max(), tag
