@@ -1287,7 +1287,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptw, const T* __restrict__ x, const T* __restrict__ beam,
                 const T* __restrict__ dot_with2, T* __restrict__ out,
                 double* __restrict__ partials, FastDims d, int band0, int tiles_per_band, int ntiles,
-                T scale, T sigmainv, cplx<T> wq1) {
+                T scale, T sigmainv, cplx<T> wq1, int defer_stores) {
     using P = InvP<T, L, E>;
     using F = typename P::F;
     constexpr int TPB = F::TPB, G = P::G, NT = P::NT;
@@ -1319,6 +1319,11 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
+    // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
+    // tile's even-bin transform instead of in one burst behind the epilogue
+    const bool dst = SPR && P::PARK && defer_stores;
+    V2 ov[(SPR && P::PARK) ? E : 1];
+    V2* oprev = nullptr;
     for (int sit = 0;; ++sit) {
         STAMP(2, sit, 0);
         const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
@@ -1347,6 +1352,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
                 F::template run<true>(vv, lds, t, ltw, [&](auto k) {
                     constexpr int K = decltype(k)::value;
+                    if constexpr (P::PARK) {
+                        if (dst && oprev) {
+#pragma unroll
+                            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) oprev[TPB * j] = ov[j];
+                        }
+                    }
                     if constexpr (K < NPA) {            // first passes: the odd-bin pieces (needed first)
                         inv_issue_slice<T, L, E, 1, (K * P::NITO) / NPA, ((K + 1) * P::NITO) / NPA>(Tb, d.nx, i0, rr, bi, y);
                     } else {                            // then this tile's x (and beam) rows for the epilogue
@@ -1437,7 +1448,8 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     val.x = zz.x * scale + sigmainv * xx.x;
                     val.y = zz.y * scale + sigmainv * xx.y;
                 }
-                orow[TPB * j] = val;
+                if constexpr (SPR && P::PARK) { if (dst) ov[j] = val; else orow[TPB * j] = val; }
+                else orow[TPB * j] = val;
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
@@ -1449,8 +1461,19 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             }
         }
         STAMP(2, sit, 11);
+        if constexpr (SPR && P::PARK) {
+            const int tid = launder((int)threadIdx.x);
+            const int g = tid / TPB, t = tid % TPB;
+            oprev = reinterpret_cast<V2*>(out + ((size_t)bl * d.nx + (i0 + g)) * d.ny) + t;
+        }
         if (vbn == vb) break;
         vb = vbn; bl = bln; i0 = i0n;
+    }
+    if constexpr (SPR && P::PARK) {
+        if (dst && oprev) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) oprev[TPB * j] = ov[j];
+        }
     }
     if constexpr (MODE >= 1) {
         __syncthreads();
@@ -1939,12 +1962,13 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
             static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
+            static const int defer = [] { const char* e = getenv("PFB_INV_DEFER"); return e ? atoi(e) : 1; }();   // A/B
 #define PFB_INVP3(MODE, BM, SP)                                                                         \
             hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE, BM, SP>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
                                (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
                                (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam,            \
                                (const T*)dot_with2, (T*)out, p->partials, d, band0, tiles_per_band,     \
-                               ntiles, (T)scale, (T)sigmainv, wq1)
+                               ntiles, (T)scale, (T)sigmainv, wq1, defer)
 #define PFB_INVP2(MODE, BM) do { if (spread) PFB_INVP3(MODE, BM, true); else PFB_INVP3(MODE, BM, false); } while (0)
 #define PFB_INVP(MODE) do { if (beam) PFB_INVP2(MODE, true); else PFB_INVP2(MODE, false); } while (0)
             p->last_npartials = grid;
