@@ -284,7 +284,11 @@ k_pcg_dir(T* __restrict__ p, const T* __restrict__ r, const double* __restrict__
 // <r',y'>; the two differ by rounding only -- the recomputed value is still what the NEXT
 // iteration uses as rnorm).  sums: <r',y'>, |x'-x|^2, |x'|^2, count(p' != 0)
 // XNT: x is read and x' written non-temporally (x is not touched again until the next update, ~20 N bytes later)
-template <typename T, int V, int U = 1, bool XNT = false>
+// REV: walk the vectors from the END.  The inverse row kernel before this one finishes on the last band (its Ap, p, r
+// rows are the freshest lines of the Infinity Cache) and the forward row kernel after it starts on the first band,
+// whose p' this kernel then has written last: one band's worth of each stream is served from that cache at both
+// boundaries instead of none.
+template <typename T, int V, int U = 1, bool XNT = false, bool REV = false>
 __global__ void __launch_bounds__(RED_BLOCK)
 k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict__ p,
                  const T* __restrict__ Ap, T* __restrict__ xn, T* __restrict__ rn,
@@ -298,13 +302,15 @@ k_pcg_update_dir(const T* __restrict__ x, const T* __restrict__ r, T* __restrict
         Pack<T, V> px[U], pr[U], pp[U], pa[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {              // all loads of the U strips in flight together
-            const size_t i = i0 + u * stride;
-            if (i < nvec) { px[u] = XNT ? ld_nt<T, V>(x, i) : ld<T, V>(x, i); pr[u] = ld<T, V>(r, i); pp[u] = ld<T, V>(p, i); pa[u] = ld<T, V>(Ap, i); }
+            const size_t ii = i0 + u * stride;
+            const size_t i = REV ? nvec - 1 - ii : ii;
+            if (ii < nvec) { px[u] = XNT ? ld_nt<T, V>(x, i) : ld<T, V>(x, i); pr[u] = ld<T, V>(r, i); pp[u] = ld<T, V>(p, i); pa[u] = ld<T, V>(Ap, i); }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const size_t i = i0 + u * stride;
-            if (i >= nvec) break;
+            const size_t ii = i0 + u * stride;
+            const size_t i = REV ? nvec - 1 - ii : ii;
+            if (ii >= nvec) break;
             Pack<T, V> ox, orr;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
@@ -553,7 +559,10 @@ static int launch_update_dir(size_t n, const T* x, const T* r, T* p, const T* Ap
         // L2 / the Infinity Cache between iterations and nt would send x to HBM (1024^2: 0.060 -> 0.066 ms per iteration)
         static const bool xnt_on = [] { const char* e = getenv("PFB_UPD_XNT"); return !e || atoi(e); }();
         const bool xnt = xnt_on && n * sizeof(T) >= ((size_t)32 << 20);
-        if (unroll == 2 && xnt)
+        static const bool rev = [] { const char* e = getenv("PFB_UPD_REV"); return !e || atoi(e); }();
+        if (unroll == 2 && xnt && rev)
+            hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2, true, true>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
+        else if (unroll == 2 && xnt)
             hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2, true>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
         else if (unroll == 2)
             hipLaunchKernelGGL((k_pcg_update_dir<T, V, 2>), dim3(G), dim3(RED_BLOCK), 0, st, x, r, p, Ap, xn, rn, alpha_dev, mdiv, nvec, ws);
