@@ -192,11 +192,17 @@ def main():
             t = torch.zeros(1, device=device)
             dist.all_reduce(t)                     # brings the communicator up (and its banner out) here
             torch.cuda.synchronize()
+            # the library's own RCCL communicator (pfb_comm_*; collective; None -> the torch hook is used)
+            from pfb_clean_amd.dist import native_comm
+            native_comm(None, device)
+            torch.cuda.synchronize()
     ctx = dict(args=args, world=world, rank=rank, device=device, use_pg=use_pg)
     out = bench_pd(ctx) if args.workload == 'pd' else bench_pcg(ctx)
     if rank == 0:
         print(json.dumps(out))
     if use_pg:
+        from pfb_clean_amd.dist import close_native_comms
+        close_native_comms()
         dist.destroy_process_group()
 
 
@@ -315,7 +321,11 @@ def bench_pcg(ctx):
     }
     if cpu:
         out["gpu_over_cpu"] = round(value / cpu["value"], 1)
-    if ctx['use_pg'] and getattr(res, 'hook_calls', 0):
+    if ctx['use_pg'] and getattr(res, 'exchange', '') == 'rccl-native':
+        out["allreduce_hook"] = {"backend": "rccl-native",
+                                 "what": "pfb_comm_allreduce: RCCL all-reduce of 4-7 fp64 scalars enqueued from C on the "
+                                         "solver's stream (no host callback)"}
+    elif ctx['use_pg'] and getattr(res, 'hook_calls', 0):
         out["allreduce_hook"] = {"backend": os.environ.get('PFB_DIST_BACKEND', 'nccl'), "calls_per_solve": res.hook_calls,
                                  "host_us_per_call": round(1e6 * res.hook_host_s / res.hook_calls, 2),
                                  "what": "ctypes callback -> torch.distributed.all_reduce of 4-7 fp64 scalars on the solver's stream"}

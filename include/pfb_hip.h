@@ -211,6 +211,29 @@ int pfb_pcg_solve(pfb_conv_plan* plan, int band0, int nb,
                   void* work, pfb_allreduce_fn allreduce, void* allreduce_ctx,
                   pfb_pcg_result* result, void* stream);
 
+/* ------------------------------------------------ band-shard exchange (RCCL, called from C)
+ * The reference sums the CG inner products over ALL bands inside one process
+ * (pfb/opt/pcg.py:92-107 on (nband, nx, ny) arrays); with one process per GPU and the bands sharded
+ * (pfb/opt/pcg.py:320-356 is the reference's per-band parallelism) those sums need one all-reduce
+ * of 3..7 doubles per iteration.  pfb_comm_allreduce is a ready-made pfb_allreduce_fn (ctx = the
+ * communicator): an RCCL all-reduce enqueued on the solver's own stream, nothing on the host per
+ * iteration.  RCCL is bound at run time (the copy already loaded in the process -- PyTorch's --
+ * else librccl.so.1; pfb_comm_bind names one explicitly); single-GPU callers never load it.
+ *
+ *   rank 0: pfb_comm_unique_id(id)  -> ship the 128 bytes to every rank (any channel)
+ *   all   : pfb_comm_init(rank, nranks, id, &comm)   collective, binds to the CURRENT device
+ *           pfb_pcg_solve(..., pfb_comm_allreduce, comm, ...)
+ *           pfb_comm_destroy(comm)
+ */
+#define PFB_COMM_ID_BYTES 128
+typedef struct pfb_comm pfb_comm;
+int pfb_comm_bind(const char* librccl_path);            /* optional; NULL = default search */
+int pfb_comm_unique_id(void* id128);
+int pfb_comm_init(int rank, int nranks, const void* id128, pfb_comm** out);
+int pfb_comm_destroy(pfb_comm* comm);
+int pfb_comm_info(const pfb_comm* comm, int* rank, int* nranks, int* device, int* rccl_version);
+int pfb_comm_allreduce(void* comm, double* dev_buf, int count, void* stream);
+
 /* ----------------------------------------------------------- wavelets / prox / PD
  * Replaces pfb/wavelets/wavelets.py:175-213 (dwt2d), :261-315 (idwt2d) and
  * pfb/operators/psi.py:187-256 (psi_band.dot / hdot) over all (band, basis) pairs.

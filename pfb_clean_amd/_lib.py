@@ -19,6 +19,7 @@ PCG_STATUS = {0: 'converged', 1: 'maxit', 2: 'zero-residual', 3: 'breakdown'}
 REDUCE_WS_DOUBLES = 8192
 
 
+PFB_ERR_INVALID = -1
 PFB_ERR_UNSUPPORTED = -2
 
 
@@ -58,6 +59,12 @@ SIGNATURES = {
     'pfb_pcg_work_bytes': (_sz, [_vp, _i]),
     'pfb_pcg_solve': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _d, _d, _i, _i, _i,
                            _vp, ALLREDUCE_FN, _vp, C.POINTER(PcgResult), _vp]),
+    'pfb_comm_bind': (_i, [C.c_char_p]),
+    'pfb_comm_unique_id': (_i, [_vp]),
+    'pfb_comm_init': (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    'pfb_comm_destroy': (_i, [_vp]),
+    'pfb_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'pfb_comm_allreduce': (_i, [_vp, _vp, _i, _vp]),
     'pfb_psi_plan_create': (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_d), _i, _i,
                                  C.POINTER(_vp)]),
     'pfb_psi_plan_destroy': (_i, [_vp]),

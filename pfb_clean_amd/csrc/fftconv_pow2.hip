@@ -92,8 +92,15 @@ template <> struct FastCfg<double> { static constexpr int ECOL = 8; static const
 // -> occupancy beats piece size for the latency-bound inverse kernel; the forward kernel
 // keeps 8 rows per workgroup (its strided side is the WRITE, full 128-byte lines).
 template <typename T, int L, int E, int GMAX> constexpr int row_groups();
+#ifndef PFB_ROW_E64_INV          // experiment knobs: elements per thread of the fp64 row kernels at L >= 4096
+#define PFB_ROW_E64_INV 8
+#endif
+#ifndef PFB_ROW_E64_FWD
+#define PFB_ROW_E64_FWD 8
+#endif
 template <typename T, int L, bool INVK> struct RowCfg {
-    static constexpr int EMAX = INVK ? 8 : (sizeof(T) == 4 ? 16 : 8);
+    static constexpr int EMAX = sizeof(T) == 4 ? (INVK ? 8 : 16)
+                                               : (L >= 4096 ? (INVK ? PFB_ROW_E64_INV : PFB_ROW_E64_FWD) : 8);
     static constexpr int E = (L / 64 < 8) ? 8 : (L / 64 > EMAX ? EMAX : L / 64);
     static constexpr int TPB = L / E;
     static constexpr bool WAVE = TPB <= 64;
@@ -1129,14 +1136,19 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
     const bool dot_is_x = dot_with == x;            // PCG: <p, A p> with x = p
     // fp64: 2 x 32 more registers for the prefetched operands do not exist under the 128-VGPR cap of
     // a 1024-thread workgroup (it spilled 80-94 registers); they are read in the epilogue instead
-    constexpr bool PREF = sizeof(T) == 4 || NT < 1024;
-    V2 xq[PREF ? E : 1], rq[PREF ? E : 1];
+#ifndef PFB_INV_PREF64
+#define PFB_INV_PREF64 2
+#endif
+    constexpr bool BIG64 = sizeof(T) == 8 && E >= 16;           // 64-register operands: x only / none (knob)
+    constexpr bool PREF = sizeof(T) == 4 || (NT < 1024 && (!BIG64 || PFB_INV_PREF64 >= 1));
+    constexpr bool PREFR = PREF && (!BIG64 || PFB_INV_PREF64 >= 2);
+    V2 xq[PREF ? E : 1], rq[PREFR ? E : 1];
     row_inv_phase<T, L, E, 1>([&] {
         if constexpr (PREF) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 xq[j] = xr[TPB * j];
-                if (dr2) rq[j] = dr2[TPB * j];
+                if constexpr (PREFR) { if (dr2) rq[j] = dr2[TPB * j]; }
             }
         }
     }, Tb, twQ, ltw, lds0, lds, d.nx, i0, t, vv);
@@ -1161,7 +1173,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
             acc[0] += (double)dw.x * (double)val.x + (double)dw.y * (double)val.y;
             if (dr2) {
                 V2 d2;
-                if constexpr (PREF) d2 = rq[j]; else d2 = dr2[TPB * j];
+                if constexpr (PREFR) d2 = rq[j]; else d2 = dr2[TPB * j];
                 acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
             }
             acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;

@@ -15,8 +15,17 @@ crosses GPUs:
     the solver's stream (latency-bound).  pfb_pcg_solve calls back into
     `AllReduceHook` with the device address of the scalars; the hook wraps that memory
     as a tensor view and issues torch.distributed.all_reduce (stream-ordered, no host
-    synchronisation).
+    synchronisation).  On GPUs with the `nccl` backend the exchange does not go through
+    Python at all: `native_comm()` builds an RCCL communicator inside libpfb_hip
+    (include/pfb_hip.h: pfb_comm_*) and pfb_pcg_solve is handed the C function
+    pfb_comm_allreduce, which enqueues the all-reduce on the solver's own stream.  The
+    torch hook stays as the fallback (gloo, CPU rehearsals, PFB_NATIVE_COMM=0, or any rank
+    failing to build the communicator -- the ranks agree on the choice collectively).
 """
+import ctypes as C
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
@@ -53,6 +62,105 @@ class AllReduceHook:
         dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
         self.host_s += time.perf_counter() - t0
+
+
+class NativeComm:
+    """An RCCL communicator owned by libpfb_hip (pfb_comm_*), one per process group.  `fn` / `ctx` are what
+    pfb_pcg_solve takes as (allreduce, allreduce_ctx)."""
+
+    def __init__(self, handle, lib):
+        from . import _lib
+        self.handle = handle
+        self._lib = lib
+        self.fn = C.cast(lib.pfb_comm_allreduce, _lib.ALLREDUCE_FN)
+        self.ctx = handle
+        r, n, d, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.pfb_comm_info(handle, C.byref(r), C.byref(n), C.byref(d), C.byref(v)))
+        self.rank, self.world, self.device, self.rccl_version = r.value, n.value, d.value, v.value
+
+    def all_reduce_(self, t):
+        """In-place sum of a contiguous fp64 device tensor over the ranks, on torch's current stream."""
+        from . import _lib, _dev
+        if t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda:
+            raise TypeError("NativeComm.all_reduce_: contiguous fp64 GPU tensor expected")
+        _lib.check(self._lib.pfb_comm_allreduce(self.handle, _dev.ptr(t), t.numel(), _dev.stream()))
+        return t
+
+    def close(self):
+        if self.handle:
+            self._lib.pfb_comm_destroy(self.handle)
+            self.handle = self.ctx = None
+
+
+_native = {}          # process group -> NativeComm | None (None: tried, not available -> torch hook)
+
+
+def _loaded_rccl_path():
+    """The librccl this process already has mapped (torch's own copy), so that libpfb_hip binds the same one."""
+    try:
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'librccl' in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+def native_comm(group=None, device=None):
+    """The libpfb_hip RCCL communicator for `group` (built on first use: COLLECTIVE over the group), or None
+    when the exchange has to go through torch.distributed.  Every rank gets the same answer."""
+    if group in _native:
+        return _native[group]
+    comm = None
+    usable = (os.environ.get('PFB_NATIVE_COMM', '1') != '0' and dist.is_available() and dist.is_initialized()
+              and dist.get_backend(group) == 'nccl' and torch.cuda.is_available())
+    if usable:
+        from . import _lib
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ok, err = 1, ''
+        idbuf = (C.c_ubyte * 128)()
+        try:
+            path = _loaded_rccl_path()
+            _lib.check(lib.pfb_comm_bind(path.encode() if path else None))
+            if rank == 0:
+                _lib.check(lib.pfb_comm_unique_id(idbuf))
+        except Exception as e:      # this rank cannot: tell the others below
+            ok, err = 0, repr(e)
+        # the 128-byte id travels over the existing process group; a failed rank 0 sends zeros and flags it
+        t = torch.tensor(list(bytes(idbuf)) + [ok], dtype=torch.uint8, device=dev)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(t, src=src, group=group)
+        flag = torch.tensor([float(ok)], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if flag.item() >= 1.0 and int(t[-1].item()) == 1:
+            ids = bytes(t[:128].cpu().tolist())
+            handle = C.c_void_p()
+            with torch.cuda.device(dev):
+                code = lib.pfb_comm_init(rank, world, ids, C.byref(handle))
+            ok = 1 if code == 0 else 0
+            if not ok:
+                err = (lib.pfb_last_error() or b'').decode()
+            flag = torch.tensor([float(ok)], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if flag.item() >= 1.0:
+                comm = NativeComm(handle, lib)
+            elif ok:
+                lib.pfb_comm_destroy(handle)
+        if comm is None and err:
+            print(f"pfb_clean_amd: native RCCL communicator not available on rank {rank} ({err}); "
+                  "using the torch.distributed hook", file=sys.stderr)
+    _native[group] = comm
+    return comm
+
+
+def close_native_comms():
+    for c in _native.values():
+        if c is not None:
+            c.close()
+    _native.clear()
 
 
 def global_max(value, device, group=None):

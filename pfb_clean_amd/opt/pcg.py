@@ -160,10 +160,16 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
     r = torch.empty_like(b3) if return_resid else None
     work = _Work.get(plan, nb)
     res = _lib.PcgResult()
+    cb_ctx = None
+    native = None
+    if distributed:
+        from ..dist import AllReduceHook, native_comm
+        native = native_comm(group, b3.device) if b3.is_cuda else None
     if not distributed:
         cb = _lib.ALLREDUCE_FN(0)
+    elif native is not None:             # RCCL from C on the solver's stream: nothing on the host per iteration
+        cb, cb_ctx = native.fn, native.ctx
     else:
-        from ..dist import AllReduceHook
         allreduce = AllReduceHook(work, group)
 
         def _hook(ctx, buf, count, stream):
@@ -179,10 +185,11 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
         _lib.check(lib.pfb_pcg_solve(plan.handle, A.band0, nb, _dev.ptr(b3), _dev.ptr(x), _dev.ptr(r),
                                      _dev.ptr(beam), A.wsum if A.wsum is not None else 0.0,
                                      A.sigmainv, float(mdiv), float(tol), int(maxit), int(minit),
-                                     _backtrack_mode(backtrack), _dev.ptr(work), cb, None, C.byref(res),
+                                     _backtrack_mode(backtrack), _dev.ptr(work), cb, cb_ctx, C.byref(res),
                                      _dev.stream()))
-    if distributed:                  # bench.py reports what the hook costs the host
-        res.hook_calls, res.hook_host_s = allreduce.calls, allreduce.host_s
+    if distributed:                  # bench.py reports which exchange ran and what the hook costs the host
+        res.exchange = 'rccl-native' if native is not None else 'torch-hook'
+        res.hook_calls, res.hook_host_s = (0, 0.0) if native is not None else (allreduce.calls, allreduce.host_s)
     if plan.embed is not None:
         x = x[:, :plan.nx, :plan.ny].contiguous()
         r = None if r is None else r[:, :plan.nx, :plan.ny].contiguous()

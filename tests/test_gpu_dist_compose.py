@@ -50,15 +50,49 @@ def test_pcg_allreduce_hook_with_rccl_world1():
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(_free_port())
     dist.init_process_group('nccl', rank=0, world_size=1)
+    from pfb_clean_amd import dist as pdist
     try:
+        # (1) the library's own RCCL communicator: all-reduce enqueued from C on the solver's stream
+        comm = pdist.native_comm()
+        assert comm is not None and comm.world == 1 and comm.rank == 0 and comm.rccl_version > 20000
+        t = torch.arange(7, dtype=torch.float64, device='cuda') + 0.5
+        assert torch.equal(comm.all_reduce_(t.clone()), t)
         x, _, res = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True)
+        assert res.exchange == 'rccl-native'
         x1, _, res1 = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True,
                                 backtrack='exact')
+        # (2) the fallback: ctypes callback -> torch.distributed.all_reduce
+        pdist.close_native_comms()
+        os.environ['PFB_NATIVE_COMM'] = '0'
+        try:
+            assert pdist.native_comm() is None
+            xh, _, resh = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True)
+            assert resh.exchange == 'torch-hook' and resh.hook_calls > 0
+        finally:
+            del os.environ['PFB_NATIVE_COMM']
+            pdist.close_native_comms()
     finally:
+        pdist.close_native_comms()
         dist.destroy_process_group()
-    assert res.iters == res_ref.iters == 8
+    assert res.iters == res_ref.iters == resh.iters == 8
     assert torch.equal(x, x_ref)                   # sum over one rank: bitwise identical
+    assert torch.equal(xh, x_ref)
     assert (x1 - x_ref).abs().max().item() < 1e-12 * x_ref.abs().max().item()
+
+
+def test_comm_entry_points_reject_bad_arguments():
+    from pfb_clean_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p()
+    ids = bytes(128)
+    assert lib.pfb_comm_init(0, 0, ids, C.byref(h)) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_init(2, 2, ids, C.byref(h)) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_init(0, 1, None, C.byref(h)) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_unique_id(None) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_allreduce(None, None, 4, None) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_info(None, None, None, None, None) == _lib.PFB_ERR_INVALID
+    assert lib.pfb_comm_destroy(None) == 0
 
 
 def test_fwdbwd_composition_config4_reduced():
