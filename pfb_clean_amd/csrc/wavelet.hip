@@ -71,6 +71,26 @@ namespace pfb {
 static inline int coeff_size(int n, int F) { return (n + F - 1) / 2; }
 static inline int signal_size(int c, int F) { return 2 * c - F + 2; }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs by linear id, so tiles that are neighbours
+// along the contiguous axis (blockIdx.x) land in 8 different L2s: the rows of the packed coefficient plane are NOT
+// line aligned (odd Cx, ld 2068), every 128-byte tile row straddles two lines, and each L2 then writes back (or
+// fetches) its own partial copy of the shared line.  Within every run of 64 consecutive workgroups the 8 that share an
+// XCD (ids j, j + 8, .. j + 56) are given 8 CONSECUTIVE tiles instead (speed only: any bijection is correct).
+struct TileId { int x, y, z; };
+__device__ __forceinline__ TileId xcd_tile(bool on) {
+    TileId t{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    if (!on) return t;
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned total = gx * gy * gridDim.z;
+    unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (L < (total & ~63u)) L = (L & ~63u) + ((L & 7u) << 3) + ((L >> 3) & 7u);
+    t.x = (int)(L % gx);
+    const unsigned q = L / gx;
+    t.y = (int)(q % gy);
+    t.z = (int)(q / gy);
+    return t;
+}
+
 // ------------------------------------------------------------------ 'self' basis
 // dst[c][r] = src[r][c]   (src R x C, ld ls; dst ld ld); ACC adds instead of storing
 template <typename T, bool ACC>
@@ -100,129 +120,190 @@ k_transpose(const T* __restrict__ src, size_t src_band, int ls, T* __restrict__ 
 // is fully unrolled so that ALL global loads of a thread are in flight before the first LDS
 // store (a rolled load-wait-store loop pays the HBM latency once per trip: 104 us -> see
 // DESIGN.md), and the tap loops are unrolled FMA chains.
+// layout of the register-blocked tile (dwt_tile_fast below), shared with the host's LDS sizing
+template <typename T> struct DwtFast {
+    static constexpr int EV = 16 / (int)sizeof(T);          // elements per 16-byte access
+    static constexpr int QB = 2 * EV;                       // y-pass outputs (per filter) of one work item
+    // samples between the 16-byte aligned start of the staged window and the tile's first sample: the first sample is
+    // global y = 2 oy0 + 2 - F with oy0 a multiple of the tile edge, i.e. 2 - F modulo the vector width
+    static constexpr int off(int F) { return (EV == 4 && F % 4 == 0) ? 2 : 0; }
+    static constexpr int nrd(int F) { return (QB + F / 2 - 1 + off(F) / 2 + EV - 1) / EV; }     // 16-byte reads per parity
+    // samples of one parity per tile row, padded so that (a) the last item's reads stay inside the row and (b) lanes
+    // walking down the rows hit disjoint banks with 16-byte reads (row stride = 4 * odd words modulo 64)
+    static constexpr int sa(int TA, int F) {
+        int v = TA - QB + nrd(F) * EV;
+        const int m = EV == 4 ? 8 : 4, r = EV == 4 ? 4 : 2;
+        while (v % m != r) v += EV;
+        return v;
+    }
+    static constexpr int ni(int TA, int F) { return 2 * TA + F - 2; }
+    static constexpr int sb(int TA) { return 2 * TA + EV; }                                       // B row: lo | hi | pad
+    static constexpr int bo(int TA, int F) {                                                      // odd-row half of B
+        const int w = 64 / (EV == 4 ? 1 : 2), half = 32 / (EV == 4 ? 1 : 2);                      // 64 / 32 banks in elements
+        return (ni(TA, F) / 2 * sb(TA) + w - 1) / w * w + half;
+    }
+    static constexpr size_t elems(int TA, int F) {
+        return (size_t)2 * ni(TA, F) * sa(TA, F) + (size_t)bo(TA, F) + (size_t)(ni(TA, F) / 2) * sb(TA);
+    }
+};
+
+template <typename T, int F, int TA>
+__device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                         const T* __restrict__ src, int ldin, int nxin, int nyin,
+                                         T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
+                                         int ox0, int oy0, bool allow_fast = true);
+
 template <typename T, int F, int TA>
 __global__ void __launch_bounds__(256)
 k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int nyin,
             T* __restrict__ coeffs, size_t c_band, int ldc, int Cx, int Cy,
             T* __restrict__ approx, size_t a_band, Filt<T> f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
-    // Both passes decimate by two (index 2q + d): with a plain row the 32 lanes of a half-wave touch only 16
-    // banks (2-way conflicts, 46 % of the LDS-busy cycles in rocprofv3).  A and B are therefore stored
-    // PARITY-SPLIT along the decimated axis -- even samples / rows first, odd ones AO / BO elements later --
-    // so that a tap of fixed parity walks consecutive addresses.
-    constexpr int SA = NI / 2;                // samples of one parity per tile row (NI is even)
-    constexpr int AO = NI * SA;               // offset of the odd-sample half of A
-    constexpr int SB = 2 * TA + 1;
-    constexpr int BO = (NI / 2) * SB;         // offset of the odd-row half of B
-    T* A = reinterpret_cast<T*>(smem);        // [NI][SA]   input tile  A[lx][ly]
-    T* B = A + 2 * AO;                        // [NI][SB]   after the y pass  B[lx][q] (rows parity-split)
-    T* LL = A;                                // [TA][TA+1] LL quadrant for the approx copy: aliases A, which is dead
-                                              // after the y pass (42 -> 38 KB at F = 8: four workgroups per CU, not three)
-    const T* src = in + (size_t)blockIdx.z * in_band;
-    T* dst = coeffs + (size_t)blockIdx.z * c_band;
-    const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
-    const int gx0 = 2 * ox0 + 1 - (F - 1), gy0 = 2 * oy0 + 1 - (F - 1);
-    T lo[F], hi[F];
+    dwt_tile<T, F, TA>(reinterpret_cast<T*>(smem), f.lo, f.hi, in + (size_t)blockIdx.z * in_band, ldin, nxin, nyin,
+                       coeffs + (size_t)blockIdx.z * c_band, ldc, Cx, Cy,
+                       approx ? approx + (size_t)blockIdx.z * a_band : nullptr, blockIdx.x * TA, blockIdx.y * TA);
+}
+
+// Register-blocked tile for 16-byte aligned input rows (the finest level of an image whose width is a multiple of
+// the vector width -- the level that carries 3/4 of the work).  The plain tile below spends one LDS read and a few
+// address / guard instructions per tap and output; rocprofv3 and the ISA say the level kernel is ISSUE bound (its
+// load, LDS and store phases add up).  Here
+//   * staging writes each 16-byte global vector as two 8-byte LDS stores (even | odd samples), no per-sample guard;
+//   * the y pass gives a work item one tile row and QB consecutive outputs of BOTH filters: 2 nrd 16-byte LDS reads
+//     feed QB * F packed FMAs (the (lo, hi) pair of a tap is one v_pk_fma_f32 operand);
+//   * the x pass gives a work item one output column and EV consecutive rows of B: F 16-byte reads per 2 EV outputs,
+//     lanes along the column index so that the global stores stay coalesced and B (row stride 2TA + EV) is read
+//     without bank conflicts.
+template <typename T, int F, int TA>
+__device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                              const T* __restrict__ src, int ldin, int nxin, int nyin,
+                                              T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
+                                              int ox0, int oy0) {
+    using D = DwtFast<T>;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int EV = D::EV, QB = D::QB, H = F / 2;
+    constexpr int NI = D::ni(TA, F), OFF = D::off(F), OFFH = OFF / 2, NRD = D::nrd(F);
+    constexpr int SA = D::sa(TA, F), AO = NI * SA, SB = D::sb(TA), BO = D::bo(TA, F);
+    struct alignas(16) Vec { T e[EV]; };
+    struct alignas(8) Half { T e[EV / 2]; };
+    T* A = smem;                                    // [2 parities][NI rows][SA]
+    T* B = A + 2 * AO;                              // [2 row parities][NI / 2][SB]
+    T* LL = A;                                      // [TA][TA + 1], after the y pass
+    const int tid = threadIdx.x;
+    const int gx0 = 2 * ox0 + 2 - F, ga = 2 * oy0 + 2 - F - OFF;       // first input row; 16-byte aligned window start
+    T2 f2[F];
 #pragma unroll
-    for (int j = 0; j < F; ++j) { lo[j] = f.lo[j]; hi[j] = f.hi[j]; }
-    // 1. stage the input tile (zero extension outside the signal)
-    constexpr int VW = 16 / (int)sizeof(T);                      // elements per 16-byte access
-    if (ldin % VW == 0 && nyin % VW == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        // rows are 16-byte aligned (the finest level of an image whose width is a multiple of 4):
-        // aligned 16-byte loads of a slightly wider window -- 4x fewer load instructions, and every
-        // vector lies entirely inside or entirely outside [0, nyin)
-        struct alignas(16) Vec { T e[VW]; };
-        const int ga = gy0 - (((gy0 % VW) + VW) % VW);           // window start, rounded down
-        constexpr int NWV = (NI + 2 * (VW - 1) + VW - 1) / VW;   // vectors per tile row (upper bound)
+    for (int j = 0; j < F; ++j) { f2[j].x = flo[j]; f2[j].y = fhi[j]; }
+    // 1. stage: vector w of tile row lx holds samples ga + EV w .. + EV - 1 (entirely inside or outside [0, nyin))
+    {
+        constexpr int NWV = (NI + OFF + EV - 1) / EV;
+        static_assert(NWV * (EV / 2) <= SA, "staged row fits");
         constexpr int NLV = (NI * NWV + 255) / 256;
         Vec stage[NLV];
 #pragma unroll
         for (int k = 0; k < NLV; ++k) {
-            const int e = threadIdx.x + 256 * k;
+            const int e = tid + 256 * k;
             const int lx = e / NWV, w = e - lx * NWV;
-            const int gx = gx0 + lx, gy = ga + VW * w;
+            const int gx = gx0 + lx, gy = ga + EV * w;
             Vec v;
 #pragma unroll
-            for (int c = 0; c < VW; ++c) v.e[c] = 0;
+            for (int c = 0; c < EV; ++c) v.e[c] = 0;
             if (e < NI * NWV && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin)
                 v = *reinterpret_cast<const Vec*>(src + (size_t)gx * ldin + gy);
             stage[k] = v;
         }
 #pragma unroll
         for (int k = 0; k < NLV; ++k) {
-            const int e = threadIdx.x + 256 * k;
+            const int e = tid + 256 * k;
             const int lx = e / NWV, w = e - lx * NWV;
-            const int ly0 = ga - gy0 + VW * w;
             if (e < NI * NWV) {
+                Half ev, od;
 #pragma unroll
-                for (int c = 0; c < VW; ++c)
-                    if (ly0 + c >= 0 && ly0 + c < NI) A[((ly0 + c) & 1) * AO + lx * SA + ((ly0 + c) >> 1)] = stage[k].e[c];
+                for (int c = 0; c < EV / 2; ++c) { ev.e[c] = stage[k].e[2 * c]; od.e[c] = stage[k].e[2 * c + 1]; }
+                T* a = A + lx * SA + (EV / 2) * w;
+                *reinterpret_cast<Half*>(a) = ev;
+                *reinterpret_cast<Half*>(a + AO) = od;
             }
         }
-    } else {
-        constexpr int NLD = (NI * NI + 255) / 256;
-        T stage[NLD];
+    }
+    __syncthreads();
+    // 2. y pass: B[lx][q] = sum_m f[F-1-2m] Ae[lx][q+m] + f[F-2-2m] Ao[lx][q+m]  (q < TA: lo, TA + q: hi)
+    {
+        constexpr int NQB = TA / QB;
+        for (int it = tid; it < NI * NQB; it += 256) {
+            const int qb = it / NI, lx = it - qb * NI;              // lanes walk down the rows
+            const T* ae = A + lx * SA + qb * QB;
+            T se[NRD * EV], so[NRD * EV];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = threadIdx.x + 256 * k;
-            const int lx = e / NI, ly = e - lx * NI;
-            const int gx = gx0 + lx, gy = gy0 + ly;
-            T v = 0;
-            if (e < NI * NI && gx >= 0 && gx < nxin && gy >= 0 && gy < nyin) v = src[(size_t)gx * ldin + gy];
-            stage[k] = v;
-        }
+            for (int k = 0; k < NRD; ++k) {
+                *reinterpret_cast<Vec*>(&se[EV * k]) = *reinterpret_cast<const Vec*>(ae + EV * k);
+                *reinterpret_cast<Vec*>(&so[EV * k]) = *reinterpret_cast<const Vec*>(ae + AO + EV * k);
+            }
+            T2 acc[QB];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int e = threadIdx.x + 256 * k;
-            const int lx = e / NI, ly = e - lx * NI;
-            if (e < NI * NI) A[(ly & 1) * AO + lx * SA + (ly >> 1)] = stage[k];
+            for (int q = 0; q < QB; ++q) {
+                acc[q] = T2{0, 0};
+#pragma unroll
+                for (int m = 0; m < H; ++m) {
+                    acc[q] += f2[F - 1 - 2 * m] * se[q + m + OFFH];
+                    acc[q] += f2[F - 2 - 2 * m] * so[q + m + OFFH];
+                }
+            }
+            T* brow = B + (lx & 1) * BO + (lx >> 1) * SB + qb * QB;
+#pragma unroll
+            for (int k = 0; k < QB / EV; ++k) {
+                Vec l, h;
+#pragma unroll
+                for (int c = 0; c < EV; ++c) { l.e[c] = acc[EV * k + c].x; h.e[c] = acc[EV * k + c].y; }
+                *reinterpret_cast<Vec*>(brow + EV * k) = l;
+                *reinterpret_cast<Vec*>(brow + TA + EV * k) = h;
+            }
         }
     }
     __syncthreads();
-    // 2. y pass: B[lx][q] = sum_j filt[j] A[lx][2q' + F-1-j]   (q < TA: lo, q >= TA: hi)
-    for (int e = threadIdx.x; e < NI * TA; e += 256) {
-        const int lx = e / TA, qq = e - lx * TA;
-        const T* a = A + lx * SA + qq;
-        T sl = 0, sh = 0;
+    // 3. x pass + store: out[r][cc] = sum_m f[F-1-2m] Be[cc+m][r] + f[F-2-2m] Bo[cc+m][r]
+    {
+        const bool full = ox0 + TA <= Cx && oy0 + TA <= Cy;
+        for (int it = tid; it < TA * (2 * TA / EV); it += 256) {
+            const int rb = it / TA, cc = it - rb * TA;              // lanes along the output column index
+            const int r0 = rb * EV;
+            const T* b = B + cc * SB + r0;
+            T2 acc[EV];
 #pragma unroll
-        for (int j = 0; j < F; ++j) {                          // sample 2 qq + d, d = F-1-j
-            const int d = F - 1 - j;
-            const T v = a[(d & 1) * AO + (d >> 1)];
-            sl += lo[j] * v; sh += hi[j] * v;
-        }
-        T* brow = B + (lx & 1) * BO + (lx >> 1) * SB;
-        brow[qq] = sl;
-        brow[TA + qq] = sh;
-    }
-    __syncthreads();
-    // 3. x pass + store: out[r][c], r < 2TA (y coefficient, lo|hi), c (x coefficient) lo & hi
-    for (int e = threadIdx.x; e < 2 * TA * TA; e += 256) {
-        const int r = e / TA, cc = e - r * TA;
-        const T* b = B + cc * SB + r;
-        T sl = 0, sh = 0;
+            for (int r = 0; r < EV; ++r) acc[r] = T2{0, 0};
 #pragma unroll
-        for (int j = 0; j < F; ++j) {                          // row 2 cc + d, d = F-1-j
-            const int d = F - 1 - j;
-            const T v = b[(d & 1) * BO + (d >> 1) * SB];
-            sl += lo[j] * v; sh += hi[j] * v;
+            for (int m = 0; m < H; ++m) {
+                const Vec ve = *reinterpret_cast<const Vec*>(b + m * SB);
+                const Vec vo = *reinterpret_cast<const Vec*>(b + BO + m * SB);
+#pragma unroll
+                for (int r = 0; r < EV; ++r) {
+                    acc[r] += f2[F - 1 - 2 * m] * ve.e[r];
+                    acc[r] += f2[F - 2 - 2 * m] * vo.e[r];
+                }
+            }
+            const bool hiy = r0 >= TA;
+            const int rr0 = hiy ? r0 - TA : r0;
+            const int gx = ox0 + cc;
+            T* row = dst + (size_t)((hiy ? Cy : 0) + oy0 + rr0) * ldc + gx;
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < EV; ++r) { row[(size_t)r * ldc] = acc[r].x; row[(size_t)r * ldc + Cx] = acc[r].y; }
+            } else if (gx < Cx) {
+#pragma unroll
+                for (int r = 0; r < EV; ++r)
+                    if (oy0 + rr0 + r < Cy) { row[(size_t)r * ldc] = acc[r].x; row[(size_t)r * ldc + Cx] = acc[r].y; }
+            }
+            if (!hiy) {
+#pragma unroll
+                for (int r = 0; r < EV; ++r) LL[cc * (TA + 1) + rr0 + r] = acc[r].x;
+            }
         }
-        const bool hiy = r >= TA;
-        const int rr = hiy ? r - TA : r;
-        const int gy = oy0 + rr, gx = ox0 + cc;
-        if (gy < Cy && gx < Cx) {
-            T* row = dst + (size_t)((hiy ? Cy : 0) + gy) * ldc;
-            row[gx] = sl;
-            row[Cx + gx] = sh;
-        }
-        if (!hiy) LL[cc * (TA + 1) + rr] = sl;
     }
     if (approx) {
         __syncthreads();
-        T* ap = approx + (size_t)blockIdx.z * a_band;
-        for (int e = threadIdx.x; e < TA * TA; e += 256) {
+        for (int e = tid; e < TA * TA; e += 256) {
             const int cc = e / TA, rr = e - cc * TA;           // rr (y) fastest: coalesced
-            if (ox0 + cc < Cx && oy0 + rr < Cy) ap[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
+            if (ox0 + cc < Cx && oy0 + rr < Cy) approx[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
         }
     }
 }
@@ -248,8 +329,12 @@ template <typename T, int F, int TA>
 __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
                                          const T* __restrict__ src, int ldin, int nxin, int nyin,
                                          T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
-                                         int ox0, int oy0) {
-
+                                         int ox0, int oy0, bool allow_fast) {
+    constexpr int VW0 = 16 / (int)sizeof(T);
+    if (allow_fast && ldin % VW0 == 0 && nyin % VW0 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && TA % (2 * VW0) == 0) {
+        dwt_tile_fast<T, F, TA>(smem, flo, fhi, src, ldin, nxin, nyin, dst, ldc, Cx, Cy, approx, ox0, oy0);
+        return;
+    }
     constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
     // Both passes decimate by two (index 2q + d): with a plain row the 32 lanes of a half-wave touch only 16
     // banks (2-way conflicts, 46 % of the LDS-busy cycles in rocprofv3).  A and B are therefore stored
@@ -373,15 +458,18 @@ __global__ void __launch_bounds__(256)
 k_dwt_batched(const T* __restrict__ in_base, size_t in_band, T* __restrict__ alpha, size_t aband, int ldc,
               T* __restrict__ scr_out, size_t sband, const AnaPrm<T>* __restrict__ prm, int nwb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int j = blockIdx.z % nwb, band = blockIdx.z / nwb;
+    const bool allow_fast = !(nwb & (1 << 30));     // PFB_DWT_FAST=0 (A/B): plain tiles only
+    const TileId tl = xcd_tile(!(nwb & (1 << 29))); // PFB_PSI_XCD=0 (A/B): launch order
+    nwb &= ~(3 << 29);
+    const int j = tl.z % nwb, band = tl.z / nwb;
     const AnaPrm<T>& P = prm[j];
-    const int ox0 = blockIdx.x * TA, oy0 = blockIdx.y * TA;
+    const int ox0 = tl.x * TA, oy0 = tl.y * TA;
     if (ox0 >= P.Cx || oy0 >= P.Cy) return;
     const T* src = in_base + P.in_off + (size_t)band * in_band;
     T* dst = alpha + (size_t)band * aband + P.coeff_off;
     T* approx = P.has_approx ? scr_out + P.approx_off + (size_t)band * sband : nullptr;
     switch (P.F) {
-#define X(FF) case FF: if constexpr (FF <= FMAX) dwt_tile<T, FF, TA>(reinterpret_cast<T*>(smem_raw), P.lo, P.hi, src, P.ldin, P.nxin, P.nyin, dst, ldc, P.Cx, P.Cy, approx, ox0, oy0); break;
+#define X(FF) case FF: if constexpr (FF <= FMAX) dwt_tile<T, FF, TA>(reinterpret_cast<T*>(smem_raw), P.lo, P.hi, src, P.ldin, P.nxin, P.nyin, dst, ldc, P.Cx, P.Cy, approx, ox0, oy0, allow_fast); break;
         X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
 #undef X
         default: break;
@@ -650,9 +738,11 @@ __global__ void __launch_bounds__(256)
 k_idwt_batched(const T* __restrict__ alpha, size_t aband, int ldc, const T* __restrict__ scr_prev, size_t sband,
                T* __restrict__ out_base, size_t oband, const SynPrm<T>* __restrict__ prm, int nwb) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int j = blockIdx.z % nwb, band = blockIdx.z / nwb;
+    const TileId tl = xcd_tile(!(nwb & (1 << 29)));
+    nwb &= ~(1 << 29);
+    const int j = tl.z % nwb, band = tl.z / nwb;
     const SynPrm<T>& P = prm[j];
-    const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
+    const int ix0 = tl.x * TS, iy0 = tl.y * TS;
     if (ix0 >= P.nxw || iy0 >= P.nyw) return;
     const T* src = alpha + (size_t)band * aband + P.coeff_off;
     const T* pv = P.has_prev ? scr_prev + P.prev_off + (size_t)band * sband : nullptr;
@@ -848,6 +938,67 @@ k_pd_primal(const T* __restrict__ xp, const T* __restrict__ xout, const T* __res
     }
 }
 
+// the same with V pixels per thread and step (16-byte accesses; npix a multiple of V, 16-byte aligned arrays): the
+// scalar kernel above moved 402 MB in 119 us at config #4, 3.4 TB/s
+template <typename T, int V>
+__global__ void __launch_bounds__(256)
+k_pd_primal_vec(const T* __restrict__ xp, const T* __restrict__ xout, const T* __restrict__ xprev,
+                const T* __restrict__ g, const T* __restrict__ gsub, T tau,
+                int positivity, int nband, size_t nvec, T* __restrict__ x, double* __restrict__ ws) {
+    struct alignas(V * sizeof(T)) Vec { T e[V]; };
+    __shared__ double red[3 * 4];
+    double acc[3] = {0.0, 0.0, 0.0};
+    auto ldv = [](const T* p, size_t k) { return reinterpret_cast<const Vec*>(p)[k]; };
+    auto value = [&](size_t k, Vec& xpv) -> Vec {
+        xpv = ldv(xp, k);
+        Vec xo = ldv(xout, k), gk, r;
+#pragma unroll
+        for (int c = 0; c < V; ++c) gk.e[c] = 0;
+        if (g) gk = ldv(g, k);
+        if (gsub) { const Vec s2 = ldv(gsub, k);
+#pragma unroll
+            for (int c = 0; c < V; ++c) gk.e[c] -= s2.e[c]; }
+        if (xprev) { const Vec pr = ldv(xprev, k);
+#pragma unroll
+            for (int c = 0; c < V; ++c) xo.e[c] = T(2) * xo.e[c] - pr.e[c]; }
+#pragma unroll
+        for (int c = 0; c < V; ++c) r.e[c] = xpv.e[c] - tau * (xo.e[c] + gk.e[c]);
+        return r;
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        bool kill[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) kill[c] = false;
+        if (positivity == 2) {
+            for (int b = 0; b < nband; ++b) {
+                Vec dummy;
+                const Vec v = value((size_t)b * nvec + i, dummy);
+#pragma unroll
+                for (int c = 0; c < V; ++c) if (v.e[c] <= T(0)) kill[c] = true;
+            }
+        }
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * nvec + i;
+            Vec xpv;
+            Vec val = value(k, xpv);
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                if (positivity == 1 && val.e[c] < T(0)) val.e[c] = 0;
+                if (kill[c]) val.e[c] = 0;
+                const double d = (double)val.e[c] - (double)xpv.e[c];
+                acc[0] += d * d;
+                acc[1] += (double)val.e[c] * (double)val.e[c];
+                acc[2] += (val.e[c] != T(0)) ? 1.0 : 0.0;
+            }
+            reinterpret_cast<Vec*>(x)[k] = val;
+        }
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < 3; ++q) ws[(size_t)q * gridDim.x + blockIdx.x] = acc[q];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_final_sum3(const double* __restrict__ ws, int G, int nq, double* __restrict__ out) {
     __shared__ double red[4];
@@ -956,8 +1107,10 @@ k_idwt_finest_fused(const T* __restrict__ alpha, size_t aband, int ldc, const Fi
     T acc[NP][2];
 #pragma unroll
     for (int k = 0; k < NP; ++k) { acc[k][0] = 0; acc[k][1] = 0; }
-    const int ix0 = blockIdx.x * TS, iy0 = blockIdx.y * TS;
-    const T* ab = alpha + (size_t)blockIdx.z * aband;
+    const TileId tl = xcd_tile(!(nbasis & (1 << 29)));
+    nbasis &= ~(1 << 29);
+    const int ix0 = tl.x * TS, iy0 = tl.y * TS;
+    const T* ab = alpha + (size_t)tl.z * aband;
     for (int ib = 0; ib < nbasis; ++ib) {
         const FinBasis<T>& B = prm[ib];
         const T* src = ab + B.coeff_off;
@@ -985,7 +1138,7 @@ k_idwt_finest_fused(const T* __restrict__ alpha, size_t aband, int ldc, const Fi
             }
             continue;
         }
-        const T* pv = B.has_prev ? fin + B.prev_off + (size_t)blockIdx.z * fin_band : nullptr;
+        const T* pv = B.has_prev ? fin + B.prev_off + (size_t)tl.z * fin_band : nullptr;
         switch (B.F) {
 #define X(FF) case FF: if constexpr (FF <= FMAX) idwt_tile_acc<T, FF, TS>(smem, B, src, ldc, pv, ix0, iy0, tid, acc); break;
             X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
@@ -993,7 +1146,7 @@ k_idwt_finest_fused(const T* __restrict__ alpha, size_t aband, int ldc, const Fi
             default: break;
         }
     }
-    T* dst = xo + (size_t)blockIdx.z * xband;
+    T* dst = xo + (size_t)tl.z * xband;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int e = threadIdx.x + 256 * k;
@@ -1003,6 +1156,214 @@ k_idwt_finest_fused(const T* __restrict__ alpha, size_t aband, int ldc, const Fi
             T* q = dst + (size_t)gx * ldo + gy;
             if (gy < nyw) q[0] = acc[k][0];
             if (gy + 1 < nyw) q[1] = acc[k][1];
+        }
+    }
+}
+
+// ------------------------------------------------ lean fused finest level (second generation)
+// rocprofv3 + the ISA of the kernel above: ~4500 instructions per thread and tile, of which the arithmetic is a
+// fifth -- the staging spends ~45 SCALAR instructions per wave-row on quadrant selects, 64-bit row addresses and
+// exec-mask juggling (the CU has ONE scalar unit: 117 of the kernel's 185 us), the passes one LDS read and a few index
+// instructions per tap.  Same mathematics here, organised around instruction count:
+//   * staging: each of the four quadrants is a NC x NC rectangle, a wave takes every 4th row, the lane is the column;
+//     loads are UNCONDITIONAL from clamped addresses (scalar row base + per-lane offset) and zeroed by a select,
+//     LDS stores use compile-time offsets;
+//   * x pass: an item is one row and 2 EV consecutive m: 2 NRX 16-byte LDS reads feed 2 EV h packed FMAs whose
+//     operand pairs are (even, odd) output taps; lanes walk down the rows;
+//   * y pass: thread (ox, block of MBY m): MBY + h - 1 rows of each half, scalar conflict-free reads, results stay
+//     in registers across the bases;
+//   * 'self' needs no LDS at all under this thread mapping (a lane is an image row = a column of the y-major plane);
+//   * the tile is transposed through LDS once, at the end, and stored in full 16-byte row pieces.
+template <typename T, int TS> struct SynFast {
+    static constexpr int EV = 16 / (int)sizeof(T);
+    static constexpr int MBX = 2 * EV;                      // m per x-pass item
+    static constexpr int MBY = TS * TS / 512;               // m per thread in the y pass (256 threads, TS rows)
+    static constexpr int nc(int F) { return TS / 2 + F / 2 - 1; }
+    static constexpr int nrx(int F) { return (MBX + F / 2 - 1 + EV - 1) / EV; }
+    static constexpr int ncp(int F) { return TS / 2 - MBX + nrx(F) * EV; }       // padded half row (>= nc)
+    static constexpr int sc(int F) { return 2 * ncp(F); }
+    static constexpr int ST = TS + EV;
+    static constexpr size_t elems(int F) {
+        const size_t a = (size_t)2 * nc(F) * sc(F) + (size_t)2 * nc(F) * ST, b = (size_t)TS * ST;
+        return a > b ? a : b;
+    }
+    static constexpr bool ok = TS % (2 * MBX) == 0 && 256 % TS == 0 && MBY >= 1 && (TS / 2) % MBY == 0;
+};
+
+// rows [0, R) x lanes [0, W) of a row-major array: element (r, c) = base[(y0 + r) ld + x0 + c], zero outside
+// [0, nyv) x [0, nxv); wave wv takes rows wv, wv + 4, ...
+template <typename T, int R, int W>
+__device__ __forceinline__ void rect_load(T (&st)[(R + 3) / 4], const T* __restrict__ base, int ld, int x0, int y0,
+                                          int nxv, int nyv, int wv, int lane) {
+    const int gx = x0 + lane;
+    const bool okx = lane < W && gx < nxv;
+    const int gxc = gx < nxv ? gx : nxv - 1;
+#pragma unroll
+    for (int k = 0; k < (R + 3) / 4; ++k) {
+        const int gy = y0 + wv + 4 * k;                                // wave-uniform
+        const bool oky = wv + 4 * k < R && gy < nyv;
+        const T* row = base + (size_t)(gy < nyv ? gy : nyv - 1) * ld;
+        const T v = row[gxc];
+        st[k] = (okx && oky) ? v : T(0);
+    }
+}
+// st -> LDS: (r, c) at dst[r * rs + c * cs]
+template <typename T, int R, int W>
+__device__ __forceinline__ void rect_store(const T (&st)[(R + 3) / 4], T* dst, int rs, int cs, int wv, int lane) {
+    if (lane < W) {
+#pragma unroll
+        for (int k = 0; k < (R + 3) / 4; ++k)
+            if (wv + 4 * k < R) dst[(wv + 4 * k) * rs + lane * cs] = st[k];
+    }
+}
+
+template <typename T, int F, int TS>
+__device__ __forceinline__ void idwt_tile_acc2(T* smem, const FinBasis<T>& B, const T* __restrict__ src, int ldc,
+                                               const T* __restrict__ pv, int ix0, int iy0, int tid,
+                                               T (&acc)[2 * SynFast<T, TS>::MBY]) {
+    using S = SynFast<T, TS>;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    constexpr int EV = S::EV, h = F / 2, NC = S::nc(F), NCP = S::ncp(F), SC = S::sc(F), ST = S::ST;
+    constexpr int MBX = S::MBX, NRX = S::nrx(F), MBY = S::MBY;
+    static_assert(NC <= 64 && NCP >= NC, "a quadrant row fits a wavefront");
+    struct alignas(16) Vec { T e[EV]; };
+    T* C = smem;                                      // [2 NC][SC]: lo-x | hi-x halves at 0 / NCP
+    T* Tm = C + 2 * NC * SC;                          // [2 NC][ST] after the x pass
+    const int nax = B.nax, nay = B.nay;
+    const int mx0 = ix0 / 2, my0 = iy0 / 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // 1. stage the four quadrants (all loads first)
+    T q00[(NC + 3) / 4], q01[(NC + 3) / 4], q10[(NC + 3) / 4], q11[(NC + 3) / 4];
+    if (pv) rect_load<T, NC, NC>(q00, pv, B.ldp, my0, mx0, nay, nax, wv, lane);       // LL = previous image, (x, y) order
+    else    rect_load<T, NC, NC>(q00, src, ldc, mx0, my0, nax, nay, wv, lane);
+    rect_load<T, NC, NC>(q01, src + nax, ldc, mx0, my0, nax, nay, wv, lane);
+    rect_load<T, NC, NC>(q10, src + (size_t)nay * ldc, ldc, mx0, my0, nax, nay, wv, lane);
+    rect_load<T, NC, NC>(q11, src + (size_t)nay * ldc + nax, ldc, mx0, my0, nax, nay, wv, lane);
+    T2 L2[h], H2[h];
+#pragma unroll
+    for (int j = 0; j < h; ++j) { L2[j].x = B.lo[2 * j]; L2[j].y = B.lo[2 * j + 1]; H2[j].x = B.hi[2 * j]; H2[j].y = B.hi[2 * j + 1]; }
+    __syncthreads();                                   // the previous basis is done with the LDS
+    if (pv) rect_store<T, NC, NC>(q00, C, 1, SC, wv, lane);          // transposed: row index = lane (y), column = x
+    else    rect_store<T, NC, NC>(q00, C, SC, 1, wv, lane);
+    rect_store<T, NC, NC>(q01, C + NCP, SC, 1, wv, lane);
+    rect_store<T, NC, NC>(q10, C + NC * SC, SC, 1, wv, lane);
+    rect_store<T, NC, NC>(q11, C + NC * SC + NCP, SC, 1, wv, lane);
+    __syncthreads();
+    // 2. x pass: Tm[ry][2m + p] = sum_j lo[2j+p] C[ry][m+h-1-j] + hi[2j+p] C[ry][NCP+m+h-1-j]
+    for (int it = tid; it < 2 * NC * (TS / 2 / MBX); it += 256) {
+        const int mb = it / (2 * NC), ry = it - mb * (2 * NC);
+        const T* c = C + ry * SC + mb * MBX;
+        T a[NRX * EV], d[NRX * EV];
+#pragma unroll
+        for (int k = 0; k < NRX; ++k) {
+            *reinterpret_cast<Vec*>(&a[EV * k]) = *reinterpret_cast<const Vec*>(c + EV * k);
+            *reinterpret_cast<Vec*>(&d[EV * k]) = *reinterpret_cast<const Vec*>(c + NCP + EV * k);
+        }
+        T* t = Tm + ry * ST + 2 * mb * MBX;
+#pragma unroll
+        for (int g = 0; g < 2 * MBX / EV; ++g) {          // EV outputs = EV / 2 values of m per 16-byte store
+            Vec o;
+#pragma unroll
+            for (int u = 0; u < EV / 2; ++u) {
+                const int m = g * (EV / 2) + u;
+                T2 s = T2{0, 0};
+#pragma unroll
+                for (int j = 0; j < h; ++j) { s += L2[j] * a[m + h - 1 - j]; s += H2[j] * d[m + h - 1 - j]; }
+                o.e[2 * u] = s.x; o.e[2 * u + 1] = s.y;
+            }
+            *reinterpret_cast<Vec*>(t + EV * g) = o;
+        }
+    }
+    __syncthreads();
+    // 3. y pass: thread (ox, mb): image row ix0 + ox, pixels iy0 + 2 (mb MBY + m) + p
+    {
+        const int ox = tid % TS, mb = tid / TS;
+        const T* t = Tm + (mb * MBY) * ST + ox;
+        T a[MBY + h - 1], d[MBY + h - 1];
+#pragma unroll
+        for (int i = 0; i < MBY + h - 1; ++i) { a[i] = t[i * ST]; d[i] = t[(NC + i) * ST]; }
+#pragma unroll
+        for (int m = 0; m < MBY; ++m) {
+            T2 s = T2{0, 0};
+#pragma unroll
+            for (int j = 0; j < h; ++j) { s += L2[j] * a[m + h - 1 - j]; s += H2[j] * d[m + h - 1 - j]; }
+            acc[2 * m] += s.x; acc[2 * m + 1] += s.y;
+        }
+    }
+}
+
+template <typename T, int TS, int FMAX>
+__global__ void __launch_bounds__(256)
+k_idwt_finest_fused2(const T* __restrict__ alpha, size_t aband, int ldc, const FinBasis<T>* __restrict__ prm,
+                     int nbasis, const T* __restrict__ fin, size_t fin_band,
+                     T* __restrict__ xo, size_t xband, int ldo, int nxw, int nyw) {
+    using S = SynFast<T, TS>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
+    constexpr int MBY = S::MBY, EV = S::EV, ST = S::ST;
+    struct alignas(16) Vec { T e[EV]; };
+    T acc[2 * MBY];
+#pragma unroll
+    for (int k = 0; k < 2 * MBY; ++k) acc[k] = 0;
+    const TileId tl = xcd_tile(!(nbasis & (1 << 29)));
+    nbasis &= ~(1 << 29);
+    const int ix0 = tl.x * TS, iy0 = tl.y * TS;
+    const T* ab = alpha + (size_t)tl.z * aband;
+    for (int ib = 0; ib < nbasis; ++ib) {
+        const FinBasis<T>& B = prm[ib];
+        const T* src = ab + B.coeff_off;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                 // keep the per-basis index arithmetic inside the loop (registers)
+        if (B.K == 0) {
+            // 'self': x[gx][gy] += alpha[gy][gx]  (psi.py:229-232): lanes along gx read rows of the y-major plane
+            const int ox = tid % TS, mb = tid / TS;
+            const int gx = ix0 + ox, gy0 = iy0 + 2 * mb * MBY;
+            const int gxc = gx < nxw ? gx : nxw - 1;
+            T v[2 * MBY];
+#pragma unroll
+            for (int c = 0; c < 2 * MBY; ++c) {
+                const int gy = gy0 + c;
+                v[c] = src[(size_t)(gy < nyw ? gy : nyw - 1) * ldc + gxc];
+            }
+#pragma unroll
+            for (int c = 0; c < 2 * MBY; ++c) acc[c] += v[c];         // out-of-range outputs are never stored
+            continue;
+        }
+        const T* pv = B.has_prev ? fin + B.prev_off + (size_t)tl.z * fin_band : nullptr;
+        switch (B.F) {
+#define X(FF) case FF: if constexpr (FF <= FMAX) idwt_tile_acc2<T, FF, TS>(smem, B, src, ldc, pv, ix0, iy0, tid, acc); break;
+            X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+            default: break;
+        }
+    }
+    // tile transpose through LDS, then full 16-byte row pieces
+    T* dst = xo + (size_t)tl.z * xband;
+    {
+        const int tid = threadIdx.x;
+        const int ox = tid % TS, mb = tid / TS;
+        __syncthreads();                               // the last basis is done with the LDS
+        T* o = smem + ox * ST + 2 * mb * MBY;
+#pragma unroll
+        for (int g = 0; g < 2 * MBY / EV; ++g) {
+            Vec w;
+#pragma unroll
+            for (int c = 0; c < EV; ++c) w.e[c] = acc[EV * g + c];
+            *reinterpret_cast<Vec*>(o + EV * g) = w;
+        }
+        __syncthreads();
+        const bool vec_ok = (ldo % EV) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        for (int e = tid; e < TS * (TS / EV); e += 256) {
+            const int r = e / (TS / EV), cv = e - r * (TS / EV);
+            const int gx = ix0 + r, gy = iy0 + EV * cv;
+            if (gx >= nxw) continue;
+            const Vec w = *reinterpret_cast<const Vec*>(smem + r * ST + EV * cv);
+            T* q = dst + (size_t)gx * ldo + gy;
+            if (vec_ok && gy + EV <= nyw) *reinterpret_cast<Vec*>(q) = w;
+            else {
+#pragma unroll
+                for (int c = 0; c < EV; ++c) if (gy + c < nyw) q[c] = w.e[c];
+            }
         }
     }
 }
@@ -1020,7 +1381,9 @@ template <typename T>
 static size_t dwt_lds(int F) {
     constexpr int TA = Tile<T>::TA;
     const int NI = 2 * TA + F - 2;
-    return sizeof(T) * ((size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1));      // LL aliases A
+    const size_t plain = (size_t)NI * (NI + 1) + (size_t)NI * (2 * TA + 1);       // LL aliases A
+    const size_t fast = DwtFast<T>::elems(TA, F);                                // dwt_tile_fast (aligned input rows)
+    return sizeof(T) * (plain > fast ? plain : fast);
 }
 template <typename T>
 static size_t idwt_lds(int F) {
@@ -1152,6 +1515,10 @@ static int psi_fin_prepare(pfb_psi_plan* p) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 18>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused2<T, TS, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused2<T, TS, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_batched<T, TA, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_batched<T, TA, 18>),
@@ -1235,12 +1602,15 @@ static int psi_dot_batched_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t 
             const T* in = l == 0 ? x : (const T*)p->bscr[(l - 1) & 1];
             const size_t in_band = l == 0 ? xband : p->scratch_band;
             const AnaPrm<T>* prm = (const AnaPrm<T>*)p->ana_prm + (size_t)l * p->nwb;
+            static const bool fast = [] { const char* e = getenv("PFB_DWT_FAST"); return !e || atoi(e); }();
+            static const bool xcd = [] { const char* e = getenv("PFB_PSI_XCD"); return !e || atoi(e); }();
+            const int nwb_arg = p->nwb | (fast ? 0 : (1 << 30)) | (xcd ? 0 : (1 << 29));
             if (p->fin_fmax <= 8)
                 hipLaunchKernelGGL((k_dwt_batched<T, TA, 8>), grid, dim3(256), lds, st, in, in_band, alpha, aband,
-                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, p->nwb);
+                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, nwb_arg);
             else
                 hipLaunchKernelGGL((k_dwt_batched<T, TA, 18>), grid, dim3(256), lds, st, in, in_band, alpha, aband,
-                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, p->nwb);
+                                   p->Nxmax, (T*)p->bscr[l & 1], p->scratch_band, prm, nwb_arg);
         }
     }
     PFB_HIP_CHECK(hipGetLastError());
@@ -1256,6 +1626,7 @@ static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t 
     const size_t aband = plane * p->nbasis;
     const size_t xband = (size_t)p->nx * p->ny;
     constexpr int TS = Tile<T>::TS;
+    static const int xoff = [] { const char* e = getenv("PFB_PSI_XCD"); return (!e || atoi(e)) ? 0 : (1 << 29); }();
     if (p->nwb > 0) {
         const size_t ldsb = idwt_lds<T>(p->fin_fmax);
         for (int l = p->nlevel - 1; l >= 1; --l) {       // coarse levels: one launch per level, all bases
@@ -1265,23 +1636,35 @@ static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t 
             const size_t oband = l == 1 ? p->fin_band : p->scratch_band;
             if (p->fin_fmax <= 8)
                 hipLaunchKernelGGL((k_idwt_batched<T, TS, 8>), g, dim3(256), ldsb, st, alpha, aband, p->Nxmax,
-                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb);
+                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb | xoff);
             else
                 hipLaunchKernelGGL((k_idwt_batched<T, TS, 18>), g, dim3(256), ldsb, st, alpha, aband, p->Nxmax,
-                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb);
+                                   (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb | xoff);
         }
     }
     dim3 grid((p->nx + TS - 1) / TS, (p->ny + TS - 1) / TS, p->nband);
     size_t lds = idwt_lds<T>(p->fin_fmax);
     const size_t lds_self = sizeof(T) * (size_t)TS * (TS + 1);
     if (lds < lds_self) lds = lds_self;
-    if (p->fin_fmax <= 8)
+    static const bool fin2 = [] { const char* e = getenv("PFB_PSI_FIN2"); return !e || atoi(e); }();
+    if (fin2 && SynFast<T, TS>::ok) {
+        static_assert(SynFast<T, TS>::ok, "tile shape of the lean fused kernel");
+        const size_t lds2 = sizeof(T) * SynFast<T, TS>::elems(p->fin_fmax);
+        if (p->fin_fmax <= 8)
+            hipLaunchKernelGGL((k_idwt_finest_fused2<T, TS, 8>), grid, dim3(256), lds2, st, alpha, aband, p->Nxmax,
+                               (const FinBasis<T>*)p->fin_prm, p->nbasis | xoff, (const T*)p->fin_scratch, p->fin_band,
+                               xo, xband, p->ny, p->nx, p->ny);
+        else
+            hipLaunchKernelGGL((k_idwt_finest_fused2<T, TS, 18>), grid, dim3(256), lds2, st, alpha, aband, p->Nxmax,
+                               (const FinBasis<T>*)p->fin_prm, p->nbasis | xoff, (const T*)p->fin_scratch, p->fin_band,
+                               xo, xband, p->ny, p->nx, p->ny);
+    } else if (p->fin_fmax <= 8)
         hipLaunchKernelGGL((k_idwt_finest_fused<T, TS, 8>), grid, dim3(256), lds, st, alpha, aband, p->Nxmax,
-                           (const FinBasis<T>*)p->fin_prm, p->nbasis, (const T*)p->fin_scratch, p->fin_band,
+                           (const FinBasis<T>*)p->fin_prm, p->nbasis | xoff, (const T*)p->fin_scratch, p->fin_band,
                            xo, xband, p->ny, p->nx, p->ny);
     else
         hipLaunchKernelGGL((k_idwt_finest_fused<T, TS, 18>), grid, dim3(256), lds, st, alpha, aband, p->Nxmax,
-                           (const FinBasis<T>*)p->fin_prm, p->nbasis, (const T*)p->fin_scratch, p->fin_band,
+                           (const FinBasis<T>*)p->fin_prm, p->nbasis | xoff, (const T*)p->fin_scratch, p->fin_band,
                            xo, xband, p->ny, p->nx, p->ny);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
@@ -1569,8 +1952,22 @@ static int pd_primal_launch(int dtype, const void* xp, const void* xout, const v
     PFB_REQUIRE(xp && xout && x && sums && ws && nband > 0, PFB_ERR_INVALID, "pd_primal_update: bad argument");
     PFB_REQUIRE(!gsub || g, PFB_ERR_INVALID, "pd_primal_update: gsub given without g");
     hipStream_t st = as_stream(stream);
-    const int G = ew_grid(npix) > 1024 ? 1024 : ew_grid(npix);
-    if (dtype == PFB_F32)
+    int G = ew_grid(npix) > 1024 ? 1024 : ew_grid(npix);
+    const uintptr_t al = (uintptr_t)xp | (uintptr_t)xout | (uintptr_t)xprev | (uintptr_t)g | (uintptr_t)gsub | (uintptr_t)x;
+    const size_t V = dtype == PFB_F32 ? 4 : 2;
+    static const bool vec_on = [] { const char* e = getenv("PFB_PD_VEC"); return !e || atoi(e); }();
+    if (vec_on && (al & 15) == 0 && npix % V == 0) {          // band offsets (npix elements) stay 16-byte aligned
+        const size_t nvec = npix / V;
+        G = ew_grid(nvec) > 1024 ? 1024 : ew_grid(nvec);
+        if (dtype == PFB_F32)
+            hipLaunchKernelGGL((k_pd_primal_vec<float, 4>), dim3(G), dim3(256), 0, st, (const float*)xp, (const float*)xout,
+                               (const float*)xprev, (const float*)g, (const float*)gsub, (float)tau, positivity, nband,
+                               nvec, (float*)x, ws);
+        else
+            hipLaunchKernelGGL((k_pd_primal_vec<double, 2>), dim3(G), dim3(256), 0, st, (const double*)xp,
+                               (const double*)xout, (const double*)xprev, (const double*)g, (const double*)gsub, tau,
+                               positivity, nband, nvec, (double*)x, ws);
+    } else if (dtype == PFB_F32)
         hipLaunchKernelGGL((k_pd_primal<float>), dim3(G), dim3(256), 0, st, (const float*)xp, (const float*)xout,
                            (const float*)xprev, (const float*)g, (const float*)gsub, (float)tau, positivity, nband,
                            npix, (float*)x, ws);
