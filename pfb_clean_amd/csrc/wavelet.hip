@@ -126,8 +126,9 @@ template <typename T> struct DwtFast {
     static constexpr int QB = 2 * EV;                       // y-pass outputs (per filter) of one work item
     // samples between the 16-byte aligned start of the staged window and the tile's first sample: the first sample is
     // global y = 2 oy0 + 2 - F with oy0 a multiple of the tile edge, i.e. 2 - F modulo the vector width
-    static constexpr int off(int F) { return (EV == 4 && F % 4 == 0) ? 2 : 0; }
-    static constexpr int nrd(int F) { return (QB + F / 2 - 1 + off(F) / 2 + EV - 1) / EV; }     // 16-byte reads per parity
+    static constexpr int off(int F, bool al = true) { return (al && EV == 4 && F % 4 == 0) ? 2 : 0; }
+    // 16-byte reads per parity (the aligned layout's count also covers the unaligned one, whose window starts AT the tile)
+    static constexpr int nrd(int F) { return (QB + F / 2 - 1 + off(F) / 2 + EV - 1) / EV; }
     // samples of one parity per tile row, padded so that (a) the last item's reads stay inside the row and (b) lanes
     // walking down the rows hit disjoint banks with 16-byte reads (row stride = 4 * odd words modulo 64)
     static constexpr int sa(int TA, int F) {
@@ -174,28 +175,47 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
 //   * the x pass gives a work item one output column and EV consecutive rows of B: F 16-byte reads per 2 EV outputs,
 //     lanes along the column index so that the global stores stay coalesced and B (row stride 2TA + EV) is read
 //     without bank conflicts.
-template <typename T, int F, int TA>
-__device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
-                                              const T* __restrict__ src, int ldin, int nxin, int nyin,
-                                              T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
-                                              int ox0, int oy0) {
+// AL = false: rows of any alignment (the coarser levels read the (Cx, Cy) approximation of the level above, whose
+// row length is odd): a wave takes every 4th tile row and a lane one (even, odd) sample pair, loaded unconditionally
+// from clamped addresses and zeroed by a select -- the flat per-sample mapping of the plain tile costs ~20 instructions
+// per sample.
+// staging of a tile with the halo of an FS-tap filter (FS >= the F of every basis that will use it)
+template <typename T, int FS, int TA, bool AL>
+__device__ __forceinline__ void dwt_fast_stage(T* A, const T* __restrict__ src, int ldin, int nxin, int nyin,
+                                               int ox0, int oy0) {
     using D = DwtFast<T>;
-    typedef T T2 __attribute__((ext_vector_type(2)));
-    constexpr int EV = D::EV, QB = D::QB, H = F / 2;
-    constexpr int NI = D::ni(TA, F), OFF = D::off(F), OFFH = OFF / 2, NRD = D::nrd(F);
-    constexpr int SA = D::sa(TA, F), AO = NI * SA, SB = D::sb(TA), BO = D::bo(TA, F);
+    constexpr int EV = D::EV;
+    constexpr int NI = D::ni(TA, FS), OFF = D::off(FS, AL);
+    static_assert(AL || NI / 2 <= 64, "a tile row's sample pairs fit a wavefront");
+    constexpr int SA = D::sa(TA, FS), AO = NI * SA;
     struct alignas(16) Vec { T e[EV]; };
     struct alignas(8) Half { T e[EV / 2]; };
-    T* A = smem;                                    // [2 parities][NI rows][SA]
-    T* B = A + 2 * AO;                              // [2 row parities][NI / 2][SB]
-    T* LL = A;                                      // [TA][TA + 1], after the y pass
     const int tid = threadIdx.x;
-    const int gx0 = 2 * ox0 + 2 - F, ga = 2 * oy0 + 2 - F - OFF;       // first input row; 16-byte aligned window start
-    T2 f2[F];
+    const int gx0 = 2 * ox0 + 2 - FS, ga = 2 * oy0 + 2 - FS - OFF;     // first input row; 16-byte aligned window start
+    if constexpr (!AL) {
+        // stage, any alignment: lane = sample pair (2 lane, 2 lane + 1) of the row, wave wv rows wv, wv + 4, ..
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const int gye = ga + 2 * lane, gyo = gye + 1;
+        const bool oke = lane < NI / 2 && gye >= 0 && gye < nyin, oko = lane < NI / 2 && gyo >= 0 && gyo < nyin;
+        const int ce = gye < 0 ? 0 : (gye < nyin ? gye : nyin - 1), co = gyo < 0 ? 0 : (gyo < nyin ? gyo : nyin - 1);
+        constexpr int NR = (NI + 3) / 4;
+        T se[NR], so[NR];
 #pragma unroll
-    for (int j = 0; j < F; ++j) { f2[j].x = flo[j]; f2[j].y = fhi[j]; }
-    // 1. stage: vector w of tile row lx holds samples ga + EV w .. + EV - 1 (entirely inside or outside [0, nyin))
-    {
+        for (int k = 0; k < NR; ++k) {
+            const int lx = wv + 4 * k, gx = gx0 + lx;                    // wave-uniform
+            const bool okx = lx < NI && gx >= 0 && gx < nxin;
+            const T* row = src + (size_t)(gx < 0 ? 0 : (gx < nxin ? gx : nxin - 1)) * ldin;
+            const T ve = row[ce], vo = row[co];
+            se[k] = (okx && oke) ? ve : T(0);
+            so[k] = (okx && oko) ? vo : T(0);
+        }
+        if (lane < NI / 2) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                if (wv + 4 * k < NI) { A[(wv + 4 * k) * SA + lane] = se[k]; A[AO + (wv + 4 * k) * SA + lane] = so[k]; }
+        }
+    } else {
+        // vector w of tile row lx holds samples ga + EV w .. + EV - 1 (entirely inside or outside [0, nyin))
         constexpr int NWV = (NI + OFF + EV - 1) / EV;
         static_assert(NWV * (EV / 2) <= SA, "staged row fits");
         constexpr int NLV = (NI * NWV + 255) / 256;
@@ -226,13 +246,35 @@ __device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo
             }
         }
     }
-    __syncthreads();
-    // 2. y pass: B[lx][q] = sum_m f[F-1-2m] Ae[lx][q+m] + f[F-2-2m] Ao[lx][q+m]  (q < TA: lo, TA + q: hi)
+}
+
+// the two passes of an F-tap basis on a tile staged with the halo of FS taps (OFFS = its window offset).
+// LLB = false: the LL quadrant is collected in LDS on top of A (dead after the y pass: single-basis tiles);
+// LLB = true : A stays valid for the next basis -- LL waits in registers and goes to LDS on top of B, one barrier later.
+template <typename T, int F, int FS, int TA, int OFFS, bool LLB>
+__device__ __forceinline__ void dwt_fast_passes(T* A, T* B, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                                T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
+                                                int ox0, int oy0) {
+    using D = DwtFast<T>;
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    static_assert(F <= FS && (FS - F) % 2 == 0, "staged halo covers the basis");
+    constexpr int EV = D::EV, QB = D::QB, H = F / 2;
+    constexpr int NI = D::ni(TA, F), NIS = D::ni(TA, FS), ROFF = FS - F, OFFH = (FS - F + OFFS) / 2, NRD = D::nrd(FS);
+    constexpr int SA = D::sa(TA, FS), AO = NIS * SA, SB = D::sb(TA), BO = D::bo(TA, FS);
+    static_assert(TA - QB + QB + H - 1 + OFFH <= SA, "reads stay inside a staged row");
+    struct alignas(16) Vec { T e[EV]; };
+    T* LL = LLB ? B : A;                            // [TA][TA + 1]
+    const int tid = threadIdx.x;
+    T2 f2[F];
+#pragma unroll
+    for (int j = 0; j < F; ++j) { f2[j].x = flo[j]; f2[j].y = fhi[j]; }
+    if constexpr (LLB) __syncthreads();             // the previous basis has copied its LL out of B
+    // y pass: B[lb][q] = sum_m f[F-1-2m] Ae[lx][q+m] + f[F-2-2m] Ao[lx][q+m]  (q < TA: lo, TA + q: hi), lx = lb + ROFF
     {
         constexpr int NQB = TA / QB;
         for (int it = tid; it < NI * NQB; it += 256) {
-            const int qb = it / NI, lx = it - qb * NI;              // lanes walk down the rows
-            const T* ae = A + lx * SA + qb * QB;
+            const int qb = it / NI, lb = it - qb * NI;              // lanes walk down the rows
+            const T* ae = A + (lb + ROFF) * SA + qb * QB;
             T se[NRD * EV], so[NRD * EV];
 #pragma unroll
             for (int k = 0; k < NRD; ++k) {
@@ -249,7 +291,7 @@ __device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo
                     acc[q] += f2[F - 2 - 2 * m] * so[q + m + OFFH];
                 }
             }
-            T* brow = B + (lx & 1) * BO + (lx >> 1) * SB + qb * QB;
+            T* brow = B + (lb & 1) * BO + (lb >> 1) * SB + qb * QB;
 #pragma unroll
             for (int k = 0; k < QB / EV; ++k) {
                 Vec l, h;
@@ -261,10 +303,15 @@ __device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo
         }
     }
     __syncthreads();
-    // 3. x pass + store: out[r][cc] = sum_m f[F-1-2m] Be[cc+m][r] + f[F-2-2m] Bo[cc+m][r]
+    // x pass + store: out[r][cc] = sum_m f[F-1-2m] Be[cc+m][r] + f[F-2-2m] Bo[cc+m][r]
+    constexpr int NXI = TA * (2 * TA / EV), NXT = (NXI + 255) / 256;
+    T llv[LLB ? NXT : 1][EV];
     {
         const bool full = ox0 + TA <= Cx && oy0 + TA <= Cy;
-        for (int it = tid; it < TA * (2 * TA / EV); it += 256) {
+#pragma unroll
+        for (int kt = 0; kt < NXT; ++kt) {
+            const int it = tid + 256 * kt;
+            if (it >= NXI) break;
             const int rb = it / TA, cc = it - rb * TA;              // lanes along the output column index
             const int r0 = rb * EV;
             const T* b = B + cc * SB + r0;
@@ -293,7 +340,10 @@ __device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo
                 for (int r = 0; r < EV; ++r)
                     if (oy0 + rr0 + r < Cy) { row[(size_t)r * ldc] = acc[r].x; row[(size_t)r * ldc + Cx] = acc[r].y; }
             }
-            if (!hiy) {
+            if constexpr (LLB) {
+#pragma unroll
+                for (int r = 0; r < EV; ++r) llv[kt][r] = acc[r].x;
+            } else if (!hiy) {
 #pragma unroll
                 for (int r = 0; r < EV; ++r) LL[cc * (TA + 1) + rr0 + r] = acc[r].x;
             }
@@ -301,11 +351,36 @@ __device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo
     }
     if (approx) {
         __syncthreads();
+        if constexpr (LLB) {                        // B is dead now: park the LL quadrant there
+#pragma unroll
+            for (int kt = 0; kt < NXT; ++kt) {
+                const int it = tid + 256 * kt;
+                const int rb = it / TA, cc = it - rb * TA, r0 = rb * EV;
+                if (it < NXI && r0 < TA) {
+#pragma unroll
+                    for (int r = 0; r < EV; ++r) LL[cc * (TA + 1) + r0 + r] = llv[kt][r];
+                }
+            }
+            __syncthreads();
+        }
         for (int e = tid; e < TA * TA; e += 256) {
             const int cc = e / TA, rr = e - cc * TA;           // rr (y) fastest: coalesced
             if (ox0 + cc < Cx && oy0 + rr < Cy) approx[(size_t)(ox0 + cc) * Cy + oy0 + rr] = LL[cc * (TA + 1) + rr];
         }
     }
+}
+
+template <typename T, int F, int TA, bool AL = true>
+__device__ __forceinline__ void dwt_tile_fast(T* smem, const T* __restrict__ flo, const T* __restrict__ fhi,
+                                              const T* __restrict__ src, int ldin, int nxin, int nyin,
+                                              T* __restrict__ dst, int ldc, int Cx, int Cy, T* __restrict__ approx,
+                                              int ox0, int oy0) {
+    using D = DwtFast<T>;
+    T* A = smem;                                    // [2 parities][NI rows][SA]
+    T* B = A + 2 * D::ni(TA, F) * D::sa(TA, F);     // [2 row parities][NI / 2][SB]
+    dwt_fast_stage<T, F, TA, AL>(A, src, ldin, nxin, nyin, ox0, oy0);
+    __syncthreads();
+    dwt_fast_passes<T, F, F, TA, D::off(F, AL), false>(A, B, flo, fhi, dst, ldc, Cx, Cy, approx, ox0, oy0);
 }
 
 // ------------------------------------------------ level kernels batched over the bases
@@ -332,8 +407,14 @@ __device__ __forceinline__ void dwt_tile(T* smem, const T* __restrict__ flo, con
                                          int ox0, int oy0, bool allow_fast) {
     constexpr int VW0 = 16 / (int)sizeof(T);
     if (allow_fast && ldin % VW0 == 0 && nyin % VW0 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && TA % (2 * VW0) == 0) {
-        dwt_tile_fast<T, F, TA>(smem, flo, fhi, src, ldin, nxin, nyin, dst, ldc, Cx, Cy, approx, ox0, oy0);
+        dwt_tile_fast<T, F, TA, true>(smem, flo, fhi, src, ldin, nxin, nyin, dst, ldc, Cx, Cy, approx, ox0, oy0);
         return;
+    }
+    if constexpr (TA % (2 * VW0) == 0 && (2 * TA + F - 2) / 2 <= 64) {
+        if (allow_fast) {
+            dwt_tile_fast<T, F, TA, false>(smem, flo, fhi, src, ldin, nxin, nyin, dst, ldc, Cx, Cy, approx, ox0, oy0);
+            return;
+        }
     }
     constexpr int NI = 2 * TA + F - 2;        // input samples per tile edge
     // Both passes decimate by two (index 2q + d): with a plain row the 32 lanes of a half-wave touch only 16
@@ -476,6 +557,55 @@ k_dwt_batched(const T* __restrict__ in_base, size_t in_band, T* __restrict__ alp
     }
 }
 
+
+// Finest analysis level of ALL bases in one kernel (16-byte aligned image rows).  Launched basis by basis, level 0
+// reads the image once per wavelet basis and the 'self' basis costs a transpose kernel of its own (read + write of the
+// image): here a workgroup stages its image tile ONCE with the halo of the longest filter, writes the 'self' plane
+// straight from that tile and runs the two passes of every wavelet basis on it.
+template <typename T, int TA, int FS>
+__global__ void __launch_bounds__(256)
+k_dwt_l1_fused(const T* __restrict__ x, size_t xband, int ldin, int nxin, int nyin, T* __restrict__ alpha, size_t aband,
+               int ldc, T* __restrict__ scr_out, size_t sband, const AnaPrm<T>* __restrict__ prm, int nwb,
+               long long self_off) {
+    using D = DwtFast<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* A = reinterpret_cast<T*>(smem_raw);
+    constexpr int NIS = D::ni(TA, FS), SA = D::sa(TA, FS), AO = NIS * SA, OFFS = D::off(FS, true);
+    T* B = A + 2 * AO;
+    const TileId tl = xcd_tile(!(nwb & (1 << 29)));
+    nwb &= ~(1 << 29);
+    const int band = tl.z;
+    const int ox0 = tl.x * TA, oy0 = tl.y * TA;
+    dwt_fast_stage<T, FS, TA, true>(A, x + (size_t)band * xband, ldin, nxin, nyin, ox0, oy0);
+    __syncthreads();
+    if (self_off >= 0 && 2 * ox0 < nxin && 2 * oy0 < nyin) {
+        // 'self': alpha_self[gy][gx] = x[gx][gy] for the tile's own 2TA x 2TA pixels (psi.py:199-202)
+        T* sp = alpha + (size_t)band * aband + self_off;
+        constexpr int W = 2 * TA, RPT = W / (256 / W);
+        const int gxl = threadIdx.x % W, yq = threadIdx.x / W;
+        const int gx = 2 * ox0 + gxl;
+        const T* a = A + (gxl + FS - 2) * SA;
+        if (gx < nxin) {
+#pragma unroll
+            for (int c = 0; c < RPT; ++c) {
+                const int yy = yq * RPT + c, sidx = yy + FS - 2 + OFFS, gy = 2 * oy0 + yy;
+                if (gy < nyin) sp[(size_t)gy * ldc + gx] = a[(sidx & 1) * AO + (sidx >> 1)];
+            }
+        }
+    }
+    for (int j = 0; j < nwb; ++j) {
+        const AnaPrm<T>& P = prm[j];
+        if (ox0 >= P.Cx || oy0 >= P.Cy) continue;                   // workgroup-uniform
+        T* dst = alpha + (size_t)band * aband + P.coeff_off;
+        T* approx = P.has_approx ? scr_out + P.approx_off + (size_t)band * sband : nullptr;
+        switch (P.F) {
+#define X(FF) case FF: if constexpr (FF <= FS) dwt_fast_passes<T, FF, FS, TA, OFFS, true>(A, B, P.lo, P.hi, dst, ldc, P.Cx, P.Cy, approx, ox0, oy0); break;
+            X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+            default: break;
+        }
+    }
+}
 
 // ----------------------------------------------------------------- synthesis level
 // ---- staging of a synthesis tile's coefficients: C[ry][cx], ry, cx < 2NC (lo | hi halves in both)
@@ -1217,8 +1347,43 @@ __device__ __forceinline__ void rect_store(const T (&st)[(R + 3) / 4], T* dst, i
     }
 }
 
-template <typename T, int F, int TS>
-__device__ __forceinline__ void idwt_tile_acc2(T* smem, const FinBasis<T>& B, const T* __restrict__ src, int ldc,
+// a thread's 2 MBY consecutive pixels of image row ox -> LDS -> full 16-byte row pieces (scalar when the rows of
+// dst are not 16-byte aligned or at the image edge)
+template <typename T, int TS>
+__device__ __forceinline__ void tile_store_transposed(T* smem, const T (&acc)[2 * SynFast<T, TS>::MBY],
+                                                      T* __restrict__ dst, int ldo, int nxw, int nyw, int ix0, int iy0) {
+    using S = SynFast<T, TS>;
+    constexpr int MBY = S::MBY, EV = S::EV, ST = S::ST;
+    struct alignas(16) Vec { T e[EV]; };
+    const int tid = threadIdx.x;
+    const int ox = tid % TS, mb = tid / TS;
+    __syncthreads();                               // the last basis is done with the LDS
+    T* o = smem + ox * ST + 2 * mb * MBY;
+#pragma unroll
+    for (int g = 0; g < 2 * MBY / EV; ++g) {
+        Vec w;
+#pragma unroll
+        for (int c = 0; c < EV; ++c) w.e[c] = acc[EV * g + c];
+        *reinterpret_cast<Vec*>(o + EV * g) = w;
+    }
+    __syncthreads();
+    const bool vec_ok = (ldo % EV) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int e = tid; e < TS * (TS / EV); e += 256) {
+        const int r = e / (TS / EV), cv = e - r * (TS / EV);
+        const int gx = ix0 + r, gy = iy0 + EV * cv;
+        if (gx >= nxw) continue;
+        const Vec w = *reinterpret_cast<const Vec*>(smem + r * ST + EV * cv);
+        T* q = dst + (size_t)gx * ldo + gy;
+        if (vec_ok && gy + EV <= nyw) *reinterpret_cast<Vec*>(q) = w;
+        else {
+#pragma unroll
+            for (int c = 0; c < EV; ++c) if (gy + c < nyw) q[c] = w.e[c];
+        }
+    }
+}
+
+template <typename T, int F, int TS, typename PB>
+__device__ __forceinline__ void idwt_tile_acc2(T* smem, const PB& B, const T* __restrict__ src, int ldc,
                                                const T* __restrict__ pv, int ix0, int iy0, int tid,
                                                T (&acc)[2 * SynFast<T, TS>::MBY]) {
     using S = SynFast<T, TS>;
@@ -1337,35 +1502,35 @@ k_idwt_finest_fused2(const T* __restrict__ alpha, size_t aband, int ldc, const F
             default: break;
         }
     }
-    // tile transpose through LDS, then full 16-byte row pieces
-    T* dst = xo + (size_t)tl.z * xband;
-    {
-        const int tid = threadIdx.x;
-        const int ox = tid % TS, mb = tid / TS;
-        __syncthreads();                               // the last basis is done with the LDS
-        T* o = smem + ox * ST + 2 * mb * MBY;
+    tile_store_transposed<T, TS>(smem, acc, xo + (size_t)tl.z * xband, ldo, nxw, nyw, ix0, iy0);
+}
+
+// one level of one basis with the lean tile (levels >= 1 of psi^H: the partial image of the next finer level)
+template <typename T, int TS, int FMAX>
+__global__ void __launch_bounds__(256)
+k_idwt_batched2(const T* __restrict__ alpha, size_t aband, int ldc, const T* __restrict__ scr_prev, size_t sband,
+                T* __restrict__ out_base, size_t oband, const SynPrm<T>* __restrict__ prm, int nwb) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const TileId tl = xcd_tile(!(nwb & (1 << 29)));
+    nwb &= ~(1 << 29);
+    const int j = tl.z % nwb, band = tl.z / nwb;
+    const SynPrm<T>& P = prm[j];
+    const int ix0 = tl.x * TS, iy0 = tl.y * TS;
+    if (ix0 >= P.nxw || iy0 >= P.nyw) return;
+    const T* src = alpha + (size_t)band * aband + P.coeff_off;
+    const T* pv = P.has_prev ? scr_prev + P.prev_off + (size_t)band * sband : nullptr;
+    T acc[2 * SynFast<T, TS>::MBY];
 #pragma unroll
-        for (int g = 0; g < 2 * MBY / EV; ++g) {
-            Vec w;
-#pragma unroll
-            for (int c = 0; c < EV; ++c) w.e[c] = acc[EV * g + c];
-            *reinterpret_cast<Vec*>(o + EV * g) = w;
-        }
-        __syncthreads();
-        const bool vec_ok = (ldo % EV) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
-        for (int e = tid; e < TS * (TS / EV); e += 256) {
-            const int r = e / (TS / EV), cv = e - r * (TS / EV);
-            const int gx = ix0 + r, gy = iy0 + EV * cv;
-            if (gx >= nxw) continue;
-            const Vec w = *reinterpret_cast<const Vec*>(smem + r * ST + EV * cv);
-            T* q = dst + (size_t)gx * ldo + gy;
-            if (vec_ok && gy + EV <= nyw) *reinterpret_cast<Vec*>(q) = w;
-            else {
-#pragma unroll
-                for (int c = 0; c < EV; ++c) if (gy + c < nyw) q[c] = w.e[c];
-            }
-        }
+    for (int k = 0; k < 2 * SynFast<T, TS>::MBY; ++k) acc[k] = 0;
+    const int tid = threadIdx.x;
+    switch (P.F) {
+#define X(FF) case FF: if constexpr (FF <= FMAX) idwt_tile_acc2<T, FF, TS>(reinterpret_cast<T*>(smem_raw), P, src, ldc, pv, ix0, iy0, tid, acc); break;
+        X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16) X(18)
+#undef X
+        default: break;
     }
+    tile_store_transposed<T, TS>(reinterpret_cast<T*>(smem_raw), acc, out_base + P.out_off + (size_t)band * oband, P.ldo,
+                                 P.nxw, P.nyw, ix0, iy0);
 }
 
 template <typename T>
@@ -1515,9 +1680,17 @@ static int psi_fin_prepare(pfb_psi_plan* p) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused<T, TS, 18>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_batched2<T, TS, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_batched2<T, TS, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused2<T, TS, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_idwt_finest_fused2<T, TS, 18>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_l1_fused<T, TA, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_l1_fused<T, TA, 18>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_dwt_batched<T, TA, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1589,15 +1762,35 @@ static int psi_dot_batched_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t 
     const size_t aband = plane * p->nbasis;
     const size_t xband = (size_t)p->nx * p->ny;
     constexpr int TA = Tile<T>::TA;
+    // finest level of all bases (and the first 'self' plane) in one kernel when the image rows are 16-byte aligned
+    constexpr int VW = 16 / (int)sizeof(T);
+    static const bool l1f_on = [] { const char* e = getenv("PFB_DWT_L1FUSED"); return !e || atoi(e); }();
+    const bool l1_fused = l1f_on && p->nwb > 0 && p->ny % VW == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                          TA % (2 * VW) == 0;
+    long long self_off = -1;
     for (int ib = 0; ib < p->nbasis; ++ib) {
         if (p->bases[ib].K != 0) continue;
+        if (l1_fused && self_off < 0) { self_off = (long long)((size_t)ib * plane); continue; }
         dim3 grid((p->ny + 31) / 32, (p->nx + 31) / 32, p->nband);
         hipLaunchKernelGGL((k_transpose<T, false>), grid, dim3(256), 0, st, x, xband, p->ny,
                            alpha + (size_t)ib * plane, aband, p->Nxmax, p->nx, p->ny);
     }
     if (p->nwb > 0) {
         const size_t lds = dwt_lds<T>(p->fin_fmax);
-        for (int l = 0; l < p->nlevel; ++l) {
+        static const int xoffa = [] { const char* e = getenv("PFB_PSI_XCD"); return (!e || atoi(e)) ? 0 : (1 << 29); }();
+        if (l1_fused) {
+            dim3 grid(p->gx_ana[0], p->gy_ana[0], p->nband);
+            const AnaPrm<T>* prm = (const AnaPrm<T>*)p->ana_prm;
+            if (p->fin_fmax <= 8)
+                hipLaunchKernelGGL((k_dwt_l1_fused<T, TA, 8>), grid, dim3(256), sizeof(T) * DwtFast<T>::elems(TA, 8), st, x, xband,
+                                   p->ny, p->nx, p->ny, alpha, aband, p->Nxmax, (T*)p->bscr[0], p->scratch_band, prm,
+                                   p->nwb | xoffa, self_off);
+            else
+                hipLaunchKernelGGL((k_dwt_l1_fused<T, TA, 18>), grid, dim3(256), sizeof(T) * DwtFast<T>::elems(TA, 18), st, x, xband,
+                                   p->ny, p->nx, p->ny, alpha, aband, p->Nxmax, (T*)p->bscr[0], p->scratch_band, prm,
+                                   p->nwb | xoffa, self_off);
+        }
+        for (int l = l1_fused ? 1 : 0; l < p->nlevel; ++l) {
             dim3 grid(p->gx_ana[l], p->gy_ana[l], p->nband * p->nwb);
             const T* in = l == 0 ? x : (const T*)p->bscr[(l - 1) & 1];
             const size_t in_band = l == 0 ? xband : p->scratch_band;
@@ -1634,7 +1827,16 @@ static int psi_hdot_fused_t(pfb_psi_plan* p, const T* alpha, T* xo, hipStream_t 
             const SynPrm<T>* prm = (const SynPrm<T>*)p->syn_prm + (size_t)l * p->nwb;
             T* out = l == 1 ? (T*)p->fin_scratch : (T*)p->bscr[l & 1];
             const size_t oband = l == 1 ? p->fin_band : p->scratch_band;
-            if (p->fin_fmax <= 8)
+            static const bool lean = [] { const char* e = getenv("PFB_PSI_FIN2"); return !e || atoi(e); }();
+            if (lean && SynFast<T, TS>::ok) {
+                const size_t lds2 = sizeof(T) * SynFast<T, TS>::elems(p->fin_fmax);
+                if (p->fin_fmax <= 8)
+                    hipLaunchKernelGGL((k_idwt_batched2<T, TS, 8>), g, dim3(256), lds2, st, alpha, aband, p->Nxmax,
+                                       (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb | xoff);
+                else
+                    hipLaunchKernelGGL((k_idwt_batched2<T, TS, 18>), g, dim3(256), lds2, st, alpha, aband, p->Nxmax,
+                                       (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb | xoff);
+            } else if (p->fin_fmax <= 8)
                 hipLaunchKernelGGL((k_idwt_batched<T, TS, 8>), g, dim3(256), ldsb, st, alpha, aband, p->Nxmax,
                                    (const T*)p->bscr[(l + 1) & 1], p->scratch_band, out, oband, prm, p->nwb | xoff);
             else
