@@ -711,7 +711,11 @@ struct FwdP {
     // measured 0.90 vs 0.54 ms for the plain kernel: not used)
     // measured: 0.50 -> 0.42 ms at ny = 4096 (x 8 bands of 4096 rows); at ny = 2048 the plain
     // wave-per-row kernel (E = 16, barrier-free exchanges) is 6 % faster than this one with E = 8
-    static constexpr bool OK = E == 16 && LDS <= (size_t)160 * 1024;
+#ifndef PFB_FWDP_E8          // experiment knob: the persistent forward kernels also at 8 elements per thread (fp32 ny = 2048):
+                             // 0.0633 (sequential parities) / 0.0677 ms against 0.0561 ms for the plain kernel at 2048^2 x 4
+#define PFB_FWDP_E8 0
+#endif
+    static constexpr bool OK = (E == 16 || (PFB_FWDP_E8 && E == 8 && sizeof(T) == 4)) && LDS <= (size_t)160 * 1024;
 };
 
 template <typename T, int L, int PAR, int K, int NIT, typename Hook>
