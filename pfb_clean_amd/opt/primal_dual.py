@@ -103,6 +103,16 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     numreweight = 0
     k = 0
     xn, vn = xd, vd                               # where the newest iterate lives
+    # The host looks at three scalars per iteration (stopping rule, :150-166).  With rotating buffers on the device the
+    # NEXT iteration's analysis psi(x_new) -- which depends on nothing the host decides -- is enqueued BEFORE that look,
+    # and the look waits for an event recorded right behind the scalars' copy instead of for the whole stream: the
+    # device runs the analysis while the host reads, decides and enqueues the rest.  A converged (or failed) solve has
+    # then run one analysis too many, into the coefficient buffer that is not returned.
+    lookahead = rotate_v and group is None and not as_numpy and xd.is_cuda
+    if lookahead:
+        host_out = torch.empty(3, dtype=torch.float64).pin_memory()
+        ev = torch.cuda.Event()
+    prefetched = False
     for k in range(maxit):
         if k > 0:                                 # :176-177 of the previous iteration
             xp, xn = xn, xp
@@ -112,7 +122,9 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
                 vp.copy_(vn)
         if k > 0:
             s_old, s_new = s_new, s_old
-        psi(xp, vn)                                                      # :135
+        if not prefetched:
+            psi(xp, vn)                                                  # :135
+        prefetched = False
         dual_update_numba(vp, vn, lam, sigma=sigma, weight=w, group=group)   # :136
         psiH(vn, s_new)                                                  # :137-138 as 2 psiH(v) - psiH(vp)
         if fused_grad:
@@ -134,7 +146,16 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
                                                   _dev.ptr(out), _dev.ptr(ws), _dev.stream()))
                 out[2] = (xn != 0).any().to(out.dtype)
             dist.all_reduce(out[:3], op=dist.ReduceOp.SUM, group=pg)
-        num, den, anyx = out[:3].tolist()
+        if lookahead:
+            host_out.copy_(out[:3], non_blocking=True)
+            ev.record()
+            if k + 1 < maxit:
+                psi(xn, vp)                   # next iteration's :135 (its xp is this xn, its vn this vp buffer)
+                prefetched = True
+            ev.synchronize()
+            num, den, anyx = host_out.tolist()
+        else:
+            num, den, anyx = out[:3].tolist()
         if anyx:
             eps = math.sqrt(num / (1e-12 + den))
         else:
