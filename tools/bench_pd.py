@@ -4,7 +4,7 @@ primal-dual iteration)."""
 import sys, time
 from functools import partial
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pfb_clean_amd.operators.psf import PsfConvPlan
 from pfb_clean_amd.operators.psi import Psi
 from pfb_clean_amd.prox.prox_21m import dual_update_numba
