@@ -4,7 +4,7 @@ Development aid: python tools/stress_psi.py [ncases] [seed]"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wavelets as owv
 from oracle import daubechies as db
 from pfb_clean_amd.operators.psi import Psi
@@ -20,6 +20,8 @@ while done < ncases:
     bases = list(rng.choice(names, size=int(rng.integers(1, 5)), replace=False))
     nl = int(rng.integers(1, 4))
     wav = [b for b in bases if b != 'self']
+    if not wav:               # 'self' alone: the reference sizes the coefficient planes from the wavelet bases (psi.py:75-78)
+        continue
     if wav and nl > min(db.dwt_max_level(min(nx, ny), w) for w in wav):
         continue
     dt = np.float64 if rng.random() < 0.5 else np.float32
