@@ -110,8 +110,13 @@ def _loaded_rccl_path():
 def native_comm(group=None, device=None):
     """The libpfb_hip RCCL communicator for `group` (built on first use: COLLECTIVE over the group), or None
     when the exchange has to go through torch.distributed.  Every rank gets the same answer."""
-    if group in _native:
-        return _native[group]
+    live = dist.is_available() and dist.is_initialized()
+    # keyed on the shape of the process group as well: a communicator outlives the torch group it was built over, and
+    # after destroy / re-init with another backend or size it must not be reused (every rank computes the same key, so
+    # building a new one below stays collective)
+    key = (group, dist.get_backend(group), dist.get_world_size(group), dist.get_rank(group)) if live else (group,)
+    if key in _native:
+        return _native[key]
     comm = None
     usable = (os.environ.get('PFB_NATIVE_COMM', '1') != '0' and dist.is_available() and dist.is_initialized()
               and dist.get_backend(group) == 'nccl' and torch.cuda.is_available())
@@ -152,7 +157,7 @@ def native_comm(group=None, device=None):
         if comm is None and err:
             print(f"pfb_clean_amd: native RCCL communicator not available on rank {rank} ({err}); "
                   "using the torch.distributed hook", file=sys.stderr)
-    _native[group] = comm
+    _native[key] = comm
     return comm
 
 
