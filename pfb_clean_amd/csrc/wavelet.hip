@@ -162,7 +162,8 @@ k_dwt_level(const T* __restrict__ in, size_t in_band, int ldin, int nxin, int ny
     extern __shared__ __attribute__((aligned(16))) char smem[];
     dwt_tile<T, F, TA>(reinterpret_cast<T*>(smem), f.lo, f.hi, in + (size_t)blockIdx.z * in_band, ldin, nxin, nyin,
                        coeffs + (size_t)blockIdx.z * c_band, ldc, Cx, Cy,
-                       approx ? approx + (size_t)blockIdx.z * a_band : nullptr, blockIdx.x * TA, blockIdx.y * TA);
+                       approx ? approx + (size_t)blockIdx.z * a_band : nullptr, blockIdx.x * TA, blockIdx.y * TA,
+                       f.F > 0);                    // F < 0 (launch_dwt, PFB_DWT_FAST=0): plain tiles only
 }
 
 // Register-blocked tile for 16-byte aligned input rows (the finest level of an image whose width is a multiple of
@@ -1567,7 +1568,10 @@ static size_t idwt_lds(int F) {
 template <typename T>
 static void launch_dwt(int F, dim3 grid, size_t lds, hipStream_t st, const T* in, size_t in_band, int ldin,
                        int nxin, int nyin, T* blk, size_t c_band, int ldc, int Cx, int Cy, T* approx,
-                       size_t a_band, const Filt<T>& f) {
+                       size_t a_band, const Filt<T>& f_in) {
+    static const bool fast = [] { const char* e = getenv("PFB_DWT_FAST"); return !e || atoi(e); }();
+    Filt<T> f = f_in;
+    if (!fast) f.F = -f.F;
     switch (F) {
 #define X(FF) case FF: hipLaunchKernelGGL((k_dwt_level<T, FF, Tile<T>::TA>), grid, dim3(256), lds, st, in, in_band, \
                                           ldin, nxin, nyin, blk, c_band, ldc, Cx, Cy, approx, a_band, f); break;
@@ -1769,7 +1773,8 @@ static int psi_dot_batched_t(pfb_psi_plan* p, const T* x, T* alpha, hipStream_t 
     constexpr int TA = Tile<T>::TA;
     // finest level of all bases (and the first 'self' plane) in one kernel when the image rows are 16-byte aligned
     constexpr int VW = 16 / (int)sizeof(T);
-    static const bool l1f_on = [] { const char* e = getenv("PFB_DWT_L1FUSED"); return !e || atoi(e); }();
+    static const bool l1f_on = [] { const char* e = getenv("PFB_DWT_L1FUSED"); const char* f = getenv("PFB_DWT_FAST");
+                                    return (!e || atoi(e)) && (!f || atoi(f)); }();     // built from the fast tile's passes
     const bool l1_fused = l1f_on && p->nwb > 0 && p->ny % VW == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                           TA % (2 * VW) == 0;
     long long self_off = -1;
