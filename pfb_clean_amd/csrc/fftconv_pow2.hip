@@ -722,6 +722,12 @@ template <typename T, int L, int PAR, int K, int NIT, typename Hook>
 __device__ __forceinline__ void post_steps(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1, cplx<T>* Tp, int nx,
                                            int bi, const Hook& hook);
 // hook(PassIdx<k>): called at the top of sweep step k (the kernel issues a slice of the next tile's loads there)
+#ifndef PFB_FWD_LIN
+#define PFB_FWD_LIN 1
+#endif
+template <typename T, int L, int PAR, typename Hook>
+__device__ __forceinline__ void fwdp_post_lin(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1,
+                                              cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi, const Hook& hook);
 template <typename T, int L, int PAR, typename Hook = NoPassHook>
 __device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1,
                                           cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
@@ -730,8 +736,12 @@ __device__ __forceinline__ void fwdp_post(const cplx<T>* zr, const cplx<T>* ltm,
     constexpr int NVB = P::NVB;
     constexpr int NBP = PAR ? P::NBO : P::NBE;
     constexpr int NIT = (NBP + P::BSTEP - 1) / P::BSTEP;
+#if PFB_FWD_LIN
+    fwdp_post_lin<T, L, PAR, Hook>(zr, ltm, wq1, Tb, nx, i0, rr, bi, hook);
+#else
     cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * NVB;
     post_steps<T, L, PAR, 0, NIT>(zr, ltm, wq1, Tp, nx, bi, hook);
+#endif
 }
 
 template <typename T, int L, int PAR, int K, int NIT, typename Hook>
@@ -764,6 +774,79 @@ __device__ __forceinline__ void post_steps(const cplx<T>* zr, const cplx<T>* ltm
         storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
         __builtin_amdgcn_sched_barrier(0);         // keep the sweeps' LDS reads from piling up (spills)
         post_steps<T, L, PAR, K + 1, NIT, Hook>(zr, ltm, wq1, Tp, nx, bi, hook);
+    }
+}
+
+// ---- the same sweep with strength-reduced addressing (PFB_FWD_LIN, default on).
+// The sweep above recomputes for every step the clamped block index, two padded LDS indices per value and a 64-bit
+// `block * nx` product for the store: per tile and thread 18 v_mad_u64_u32 / v_mul_lo_u32 (quarter-rate on CDNA) and
+// ~150 index instructions next to ~230 of arithmetic (ISA count).  A step advances m by NVB * BSTEP, a multiple of 16:
+// pad(m + 16 c) = pad(m) + 17 c, so each LDS stream is ONE base register with compile-time offsets; the store address
+// is a workgroup-uniform base (band + step, scalar unit) plus a 32-bit per-thread offset that never changes.
+// The irregular items -- m = 0 in the first even-bin step, and the last even-bin step, which holds only block NBE - 1
+// (the Nyquist column) -- are handled apart.
+template <typename T, int L, int PAR, int K, int NREG, typename Hook>
+__device__ __forceinline__ void post_steps_lin(const cplx<T>* const (&za)[FastCfg<T>::NVB], const cplx<T>* const (&zb)[FastCfg<T>::NVB],
+                                               const cplx<T>* lw, cplx<T> wq1, cplx<T>* ub, size_t ustep, unsigned voff,
+                                               bool first0, const Hook& hook) {
+    using P = FwdP<T, L>;
+    using F = typename P::F;
+    constexpr int NVB = P::NVB, MS = NVB * P::BSTEP;
+    if constexpr (K < NREG) {
+        hook(PassIdx<K>{});
+        Blk<T, NVB> o;
+#pragma unroll
+        for (int h = 0; h < NVB; ++h) {
+            cplx<T> w = lw[MS * K + h];
+            if (PAR) w = w * wq1;
+            const cplx<T> zv = za[h][F::cpad(MS * K)];
+            cplx<T> zm = zb[h][F::cpad(MS * (NREG - 1 - K))];
+            if constexpr (PAR == 0 && K == 0) { if (first0 && h == 0) zm = zv; }      // m = 0: both are z[0]
+            o.c[h] = T(0.5) * addrot<false>(addc(zv, zm), w * subc(zv, zm));
+        }
+        storeb<T, NVB>(ub + (size_t)K * ustep + voff, o);
+        __builtin_amdgcn_sched_barrier(0);
+        post_steps_lin<T, L, PAR, K + 1, NREG, Hook>(za, zb, lw, wq1, ub, ustep, voff, first0, hook);
+    }
+}
+
+template <typename T, int L, int PAR, typename Hook>
+__device__ __forceinline__ void fwdp_post_lin(const cplx<T>* zr, const cplx<T>* ltm, cplx<T> wq1,
+                                              cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
+                                              const Hook& hook) {
+    using P = FwdP<T, L>;
+    using F = typename P::F;
+    constexpr int NVB = P::NVB, BS = P::BSTEP, MS = NVB * BS;
+    constexpr int NBP = PAR ? P::NBO : P::NBE;
+    constexpr int NIT = (NBP + BS - 1) / BS;
+    constexpr int NREG = PAR ? NIT : NIT - 1;
+    static_assert(MS % 16 == 0, "a step keeps the padding phase");
+    static_assert(PAR ? (NBP == NIT * BS) : (NBP == (NIT - 1) * BS + 1), "block counts of the two sweeps");
+    cplx<T>* ub = Tb + (size_t)(PAR ? P::NBE : 0) * nx * NVB;                         // workgroup-uniform
+    const size_t ustep = (size_t)BS * nx * NVB;
+    const unsigned voff = ((unsigned)bi * (unsigned)nx + (unsigned)(i0 + rr)) * NVB;  // elements; < 2^32
+    const int m0 = NVB * bi;
+    const cplx<T>* za[NVB];
+    const cplx<T>* zb[NVB];
+#pragma unroll
+    for (int h = 0; h < NVB; ++h) {
+        za[h] = zr + F::pad(m0 + h);
+        // partner index of the LAST regular step (the lowest address of the stream): L - PAR - m - MS (NREG - 1)
+        // (m = 0 makes step 0 read index L: inside the row's padded allotment, and the value is replaced there)
+        zb[h] = zr + F::pad(L - PAR - (m0 + h) - MS * (NREG - 1));
+    }
+    post_steps_lin<T, L, PAR, 0, NREG, Hook>(za, zb, ltm + m0, wq1, ub, ustep, voff, bi == 0, hook);
+    if constexpr (PAR == 0) {
+        // the last even-bin step: block NBE - 1 = bins m = L (Nyquist: w_Q^(2L) = -1, partner z[0]) and, for NVB = 2,
+        // m = L + 1 (beyond the spectrum: zero).  Every thread stores it, like the clamped step it replaces.
+        hook(PassIdx<NREG>{});
+        const cplx<T> z0 = zr[F::pad(0)];
+        Blk<T, NVB> o;
+        o.c[0] = T(0.5) * addrot<false>(addc(z0, z0), cplx<T>(T(-1), T(0)) * subc(z0, z0));
+#pragma unroll
+        for (int h = 1; h < NVB; ++h) o.c[h] = cplx<T>(0, 0);
+        storeb<T, NVB>(ub + (size_t)(NBP - 1) * nx * NVB + (unsigned)(i0 + rr) * NVB, o);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
