@@ -1310,11 +1310,33 @@ struct InvP {
                                (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && (G == 2 || G == 4) && L >= 1024));
 };
 
+#ifndef PFB_INV_LIN
+#define PFB_INV_LIN 1
+#endif
+// strength-reduced addressing of the strided pieces (see fwdp_post_lin): the blocks of a thread are BSTEP apart, so the
+// load address is a workgroup-uniform base (band, parity, step) + a 32-bit per-thread offset that never changes, and
+// the padded LDS index of the scatter is one base + compile-time offsets.  Regular whenever BSTEP divides the odd-bin
+// block count; the even bins then have exactly one more block (the Nyquist column), fetched by every thread in the last step.
+template <typename T, int L, int E>
+constexpr bool inv_lin_ok() {
+    using P = InvP<T, L, E>;
+    // (fp32 only: 1902 instead of 2147 instructions per thread and tile, 0.613 vs 0.616 ms -- the inverse kernel is not
+    // issue bound the way the forward sweep was; the fp64 tiles measured 1 % slower with it)
+    return PFB_INV_LIN && sizeof(T) == 4 && P::NBO % P::BSTEP == 0 && P::NBE == P::NBO + 1 && P::NITO * P::BSTEP == P::NBO &&
+           P::NITE == P::NITO + 1 && (P::NVB * P::BSTEP) % 16 == 0 && P::F::TPB % 16 == 0;
+}
+template <typename T, int L, int E, int PAR, int K0, int K1>
+__device__ __forceinline__ void inv_issue_slice(const cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
+                                                Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]);
 template <typename T, int L, int E, int PAR>
 __device__ __forceinline__ void inv_issue(const cplx<T>* __restrict__ Tb, int nx, int i0, int rr, int bi,
                                           Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
     using P = InvP<T, L, E>;
     constexpr int NBP = PAR ? P::NBO : P::NBE, NIT = PAR ? P::NITO : P::NITE;
+    if constexpr (inv_lin_ok<T, L, E>()) {
+        inv_issue_slice<T, L, E, PAR, 0, NIT>(Tb, nx, i0, rr, bi, y);
+        return;
+    }
     const cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * P::NVB;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -1330,6 +1352,17 @@ __device__ __forceinline__ void inv_issue_slice(const cplx<T>* __restrict__ Tb, 
                                                 Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
     using P = InvP<T, L, E>;
     constexpr int NBP = PAR ? P::NBO : P::NBE;
+    if constexpr (inv_lin_ok<T, L, E>()) {
+        const cplx<T>* ub = Tb + (size_t)(PAR ? P::NBE : 0) * nx * P::NVB;                    // workgroup-uniform
+        const size_t ustep = (size_t)P::BSTEP * nx * P::NVB;
+        const unsigned vrow = (unsigned)(i0 + rr) * P::NVB, voff = (unsigned)bi * (unsigned)nx * P::NVB + vrow;
+#pragma unroll
+        for (int k = K0; k < K1; ++k) {
+            if (PAR == 0 && k == P::NITE - 1) y[k] = loadb<T, P::NVB>(ub + (size_t)(NBP - 1) * nx * P::NVB + vrow);   // Nyquist block
+            else y[k] = loadb<T, P::NVB>(ub + (size_t)k * ustep + voff);
+        }
+        return;
+    }
     const cplx<T>* Tp = Tb + ((size_t)(PAR ? P::NBE : 0) * nx + i0 + rr) * P::NVB;
 #pragma unroll
     for (int k = K0; k < K1; ++k) {
@@ -1344,6 +1377,18 @@ __device__ __forceinline__ void inv_scatter(const Blk<T, FastCfg<T>::NVB> (&y)[I
                                             cplx<T>* yr, int bi) {
     using P = InvP<T, L, E>;
     constexpr int NBP = PAR ? P::NBO : P::NBE, NIT = PAR ? P::NITO : P::NITE;
+    if constexpr (inv_lin_ok<T, L, E>()) {
+        cplx<T>* y0 = yr + P::F::pad(P::NVB * bi);          // pad(NVB bi + h + 16 c) = pad(NVB bi) + h + 17 c
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            if (PAR == 0 && k == NIT - 1) yr[P::F::pad(L)] = y[k].c[0];      // bin m = L; every thread holds the same value
+            else {
+#pragma unroll
+                for (int h = 0; h < P::NVB; ++h) y0[P::F::cpad(P::NVB * P::BSTEP * k) + h] = y[k].c[h];
+            }
+        }
+        return;
+    }
     // no `if (b < NBP)` here: a conditional use lets the compiler SINK the load into the branch
     // (load + vmcnt(0) back to back).  Out-of-range threads hold a copy of the last block
     // (inv_issue clamps the same way) and store the same values to the same place.
@@ -1361,6 +1406,22 @@ template <typename T, int L, int E, int PAR>
 __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm, cplx<T> wq1, int t,
                                           cplx<T> (&vv)[E]) {
     using F = typename InvP<T, L, E>::F;
+    if constexpr (inv_lin_ok<T, L, E>()) {
+        const cplx<T>* pa = lds + F::pad(t);                                  // Y[t + TPB j]      = pa[cpad(TPB j)]
+        const cplx<T>* pb = lds + F::pad(L - PAR - t - F::TPB * (E - 1));     // partner of step j = pb[cpad(TPB (E-1-j))]
+        const cplx<T>* lw = ltm + t;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            cplx<T> yv = pa[F::cpad(F::TPB * j)];
+            cplx<T> ym = pb[F::cpad(F::TPB * (E - 1 - j))];
+            if (!PAR && j == 0) { if (t == 0) { yv.y = 0; ym.y = 0; } }
+            cplx<T> w = lw[F::TPB * j];
+            if (PAR) w = w * wq1;
+            vv[j] = addrot<true>(addc(yv, ym), mulc(subc(yv, ym), w));
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < E; ++j) {
         const int m = t + F::TPB * j;
