@@ -99,7 +99,11 @@ template <typename T, int L, int E, int GMAX> constexpr int row_groups();
 #define PFB_ROW_E64_FWD 8
 #endif
 template <typename T, int L, bool INVK> struct RowCfg {
-    static constexpr int EMAX = sizeof(T) == 4 ? (INVK ? 8 : 16)
+#ifndef PFB_INV_E16          // experiment knob: 16 elements per thread (8-row tiles, 128-byte pieces) in the fp32 inverse rows at L = 2048:
+                             // 128 VGPRs + 232 B of scratch, 0.792 against 0.609 ms per 8-band launch
+#define PFB_INV_E16 0
+#endif
+    static constexpr int EMAX = sizeof(T) == 4 ? (INVK ? ((PFB_INV_E16 && L == 2048) ? 16 : 8) : 16)
                                                : (L >= 4096 ? (INVK ? PFB_ROW_E64_INV : PFB_ROW_E64_FWD) : 8);
     static constexpr int E = (L / 64 < 8) ? 8 : (L / 64 > EMAX ? EMAX : L / 64);
     static constexpr int TPB = L / E;
@@ -1340,7 +1344,7 @@ struct InvP {
     // fp64: two rows = 512 threads (the exchange buffers of four complex128 rows alone fill the LDS): with
     // one such workgroup per CU every thread may use 256 VGPRs, so the even-bin result stays in registers
     // (PARK = false) and the prefetched pieces / operands fit as well.
-    static constexpr bool PARK = sizeof(T) == 4;
+    static constexpr bool PARK = sizeof(T) == 4 && E < 16;     // (E = 16: eight rows fill the LDS, the even-bin result stays in registers)
     static constexpr int G = (sizeof(T) == 4 ? 1024 : 512) / F::TPB;
     static constexpr int NT = G * F::TPB;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
