@@ -4,7 +4,7 @@ Development aid: python tools/stress_sizes.py [ncases] [seed]"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import fftconv as ofc
 from pfb_clean_amd.operators import psf as P_, hessian as H_
 
