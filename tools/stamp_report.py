@@ -23,9 +23,12 @@ dt = torch.float64 if (len(sys.argv) > 3 and sys.argv[3] == 'f64') else torch.fl
 cdt = torch.complex128 if dt == torch.float64 else torch.complex64
 ITS, NWG, NSLOT = 4, 1024, 16
 NAMES = {
-    0: ('k_row_fwd_pow2p', ['top -> pack + w_M multiply', 'forward FFT x2 (even, odd bins)',
-                             'LDS write even + issue next x + barriers', 'post-process + store even bins',
-                             'LDS write odd + barriers', 'post-process + store odd bins', 'final barrier']),
+    # default forward kernel k_row_fwd_pow2q (parities in sequence); PFB_FWD_SEQ=0 runs k_row_fwd_pow2p, whose seven
+    # intervals are: pack + w_M multiply | both transforms | LDS write even + issue next x | even sweep | LDS write odd |
+    # odd sweep | final barrier
+    0: ('k_row_fwd_pow2q', ['top -> pack (x * beam)', 'FFT (even bins)', 'LDS write even + barriers',
+                             'post-process + store even bins', 'z w_M, FFT (odd bins) with the next rows requested per pass',
+                             'LDS write odd + post-process + store odd bins', 'final barrier']),
     1: ('k_col_pow2p', ['aw = a w, issue psf_e + next a', 'FFT (even)', 'wait psf_e, multiply', 'issue psf_o, IFFT (even)',
                         'FFT (odd)', 'wait psf_o, multiply', 'IFFT (odd)', 'combine + stores issued']),
     2: ('k_row_inv_pow2p', ['barrier (top)', 'wait y_even, scatter to LDS', 'issue y_odd + barrier', 'build (even)',
