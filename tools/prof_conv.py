@@ -1,7 +1,7 @@
 """Run a few PSF-convolution applies (development aid for rocprofv3 --pmc passes)."""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pfb_clean_amd.operators.psf import PsfConvPlan
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 1

@@ -1,6 +1,6 @@
 """fp64 / large-size functional + timing probe (development aid)."""
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pfb_clean_amd.operators.psf import PsfConvPlan
 n = int(sys.argv[1]); nb = int(sys.argv[2]); dt = torch.float64 if sys.argv[3] == 'f64' else torch.float32
 cdt = torch.complex128 if dt == torch.float64 else torch.complex64

@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pfb_clean_amd.operators.psf import PsfConvPlan
 
 def run(n, dtype, nb=1, reps=10):
