@@ -344,8 +344,22 @@ def pmc_traffic(n, nb, dtype):
         except Exception:
             continue
         c = d.get('config', {})
-        if c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
+        if c.get('workload', 'pcg') == 'pcg' and c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
             return d.get('conv_group_hbm_bytes_per_launch'), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def pmc_traffic_pd(n, nb, dtype):
+    """The same for one primal-dual iteration (`--workload pd`): profiles/*pd_hbm_traffic.json."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pd_hbm_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        c = d.get('config', {})
+        if c.get('workload') == 'pd' and c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
+            return d.get('hbm_bytes_per_iteration'), os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -523,9 +537,13 @@ def bench_pd(ctx):
     balg = s * nband * ((N + coef) + (coef + N) + 4 * coef + (2 * N + 2 * (2 * n) * (Q // 2 + 1)) + 3 * N + 4 * N) \
         + s * coef
     achieved = balg / elapsed * args.steps / 1e9
+    traffic, traffic_src = pmc_traffic_pd(n, nband, args.dtype)
     roofline = {"bound": "hbm", "kernel": "primal-dual iteration (psi^H, dual update, psi, PSF conv, primal update)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per iteration (FETCH_SIZE x2 + WRITE_SIZE over the iteration's kernels, rocprofv3 --pmc)",
+                "traffic_source": traffic_src,
+                "hbm_rate_from_traffic_GBs": round(traffic / elapsed * args.steps / 1e9, 1) if traffic else None,
                 "alg_bytes_per_iteration": balg, "ms_per_iteration": round(1e3 * elapsed / args.steps, 4),
                 "timing": "wall clock of the timed region / steps (the iteration is several launches; the host "
                           "reads three scalars per iteration)"}
