@@ -103,7 +103,11 @@ template <typename T, int L, bool INVK> struct RowCfg {
                              // 128 VGPRs + 232 B of scratch, 0.792 against 0.609 ms per 8-band launch
 #define PFB_INV_E16 0
 #endif
-    static constexpr int EMAX = sizeof(T) == 4 ? (INVK ? ((PFB_INV_E16 && L == 2048) ? 16 : 8) : 16)
+#ifndef PFB_INV_E16_4096     // 16 elements per thread in the fp32 inverse rows at L = 4096: 4 rows / 64-byte pieces instead of 2 / 32,
+                             // operands read in the epilogue (no registers left to prefetch them): 1.054 against 1.188 ms per 2 x 8192^2
+#define PFB_INV_E16_4096 1
+#endif
+    static constexpr int EMAX = sizeof(T) == 4 ? (INVK ? (((PFB_INV_E16 && L == 2048) || (PFB_INV_E16_4096 && L == 4096)) ? 16 : 8) : 16)
                                                : (L >= 4096 ? (INVK ? PFB_ROW_E64_INV : PFB_ROW_E64_FWD) : 8);
     static constexpr int E = (L / 64 < 8) ? 8 : (L / 64 > EMAX ? EMAX : L / 64);
     static constexpr int TPB = L / E;
@@ -1276,9 +1280,13 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
 #ifndef PFB_INV_PREF64
 #define PFB_INV_PREF64 2
 #endif
+#ifndef PFB_INV_PREF32E16    // x / x and r prefetched there: 188 / 492 B of scratch, 1.29 / 1.63 ms
+#define PFB_INV_PREF32E16 0
+#endif
     constexpr bool BIG64 = sizeof(T) == 8 && E >= 16;           // 64-register operands: x only / none (knob)
-    constexpr bool PREF = sizeof(T) == 4 || (NT < 1024 && (!BIG64 || PFB_INV_PREF64 >= 1));
-    constexpr bool PREFR = PREF && (!BIG64 || PFB_INV_PREF64 >= 2);
+    constexpr bool BIG32 = sizeof(T) == 4 && E >= 16 && L >= 4096;      // the same question for fp32 at 16 elements per thread
+    constexpr bool PREF = BIG32 ? PFB_INV_PREF32E16 >= 1 : (sizeof(T) == 4 || (NT < 1024 && (!BIG64 || PFB_INV_PREF64 >= 1)));
+    constexpr bool PREFR = PREF && (BIG32 ? PFB_INV_PREF32E16 >= 2 : (!BIG64 || PFB_INV_PREF64 >= 2));
     V2 xq[PREF ? E : 1], rq[PREFR ? E : 1];
     row_inv_phase<T, L, E, 1>([&] {
         if constexpr (PREF) {
