@@ -287,18 +287,28 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     // L2" going to HBM: +1 GB per 8-band launch).  aw = a .* w_P^n is formed at load time and
     // parked in registers; its live range (first FFT pair) does not overlap ev's (second pair),
     // so the peak register demand is unchanged.
-    cplx<T> vv[NVB][E], aw[NVB][E];
+#ifndef PFB_COL_PREQ2
+#define PFB_COL_PREQ2 1
+#endif
+    // PREQ2 (8192-point fp32 column pairs): a .* w_P^n is NOT parked in registers -- the second parity re-reads a
+    // (an L2 / Infinity-Cache hit: this workgroup fetched it microseconds ago) -- and its registers take the PSF slices,
+    // requested a few per FFT pass: psf_e lands during the first transform, psf_o during the second.  2.19 -> 2.00 ms
+    // per 2 x 8192^2 (128 VGPRs + 244 B of scratch; = 2 with the even-bin result round-tripping through T: 160 B,
+    // 2.03 ms).  The same idea lost on the fp64 columns (fp64-issue and LDS bound); this one is latency bound.
+    constexpr bool PREQ2 = PFB_COL_PREQ2 && sizeof(T) == 4 && H >= 8192;
+    cplx<T> vv[NVB][E], aw[PREQ2 ? 1 : NVB][PREQ2 ? 1 : E];
     {
         const cplx<T>* tw2 = twP + t;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             Blk<T, NVB> a;
             if (active) a = loadb<T, NVB>(col + NVB * TPB * j);
-            const cplx<T> w = tw2[TPB * j];
+            [[maybe_unused]] cplx<T> w;
+            if constexpr (!PREQ2) w = tw2[TPB * j];
 #pragma unroll
             for (int c = 0; c < NVB; ++c) {
                 vv[c][j] = active ? a.c[c] : cplx<T>(0, 0);
-                aw[c][j] = vv[c][j] * w;
+                if constexpr (!PREQ2) aw[c][j] = vv[c][j] * w;
             }
         }
     }
@@ -306,13 +316,22 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     // latencies of a block hide behind a transform.  Meant for the 8192-point fp64 columns (one 512-thread workgroup per
     // CU, 256 VGPRs per thread; the persistent kernel does not fit there), but vv + aw + q are 192 registers before the
     // radix-16 butterfly's own 64: 84 -> 556 bytes of scratch per lane.  Kept for the record, not compiled in.
-    constexpr bool PREQ = false && sizeof(T) == 8 && H >= 8192;
+    constexpr bool PREQ = PREQ2 || (false && sizeof(T) == 8 && H >= 8192);
+    constexpr bool QSPR = PREQ2;
+    constexpr int NPQ = F::NPASS;
     Blk<T, NVB> q[PREQ ? E : 1];
-    if constexpr (PREQ) {
+    if constexpr (PREQ && !QSPR) {
 #pragma unroll
         for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
     }
     // ---- even bins of the column transform
+    if constexpr (QSPR) {
+        F::template runN<false, NVB>(vv, lds, t, ptw, [&](auto k) {
+            constexpr int K = decltype(k)::value;
+#pragma unroll
+            for (int j = (K * E) / NPQ; j < ((K + 1) * E) / NPQ; ++j) q[j] = loadb<T, NVB>(pe + NVB * TPB * j);
+        });
+    } else
     F::template runN<false, NVB>(vv, lds, t, ptw);
 #pragma unroll
     for (int j = 0; j < E; ++j) {
@@ -321,16 +340,54 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 #pragma unroll
         for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * p.c[c];
     }
-    if constexpr (PREQ) {
+    if constexpr (PREQ && !QSPR) {
 #pragma unroll
         for (int j = 0; j < E; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
     }
+    if constexpr (QSPR) {
+        F::template runN<true, NVB>(vv, lds, t, ptw, [&](auto k) {
+            constexpr int K = decltype(k)::value;
+#pragma unroll
+            for (int j = (K * E) / NPQ; j < ((K + 1) * E) / NPQ; ++j) q[j] = loadb<T, NVB>(po + NVB * TPB * j);
+        });
+    } else
     F::template runN<true, NVB>(vv, lds, t, ptw);
-    cplx<T> ev[NVB][E];
+    // PREQ2 == 2: the even-bin result does not wait in registers either: a is re-read first, then the even-bin result
+    // takes its place in T (same addresses, same thread: the loads have landed before the stores are issued) and comes
+    // back for the final combination -- both round trips stay in the L2 / Infinity Cache
+    constexpr bool EVG = PREQ2 && PFB_COL_PREQ2 >= 2;
+    cplx<T> ev[EVG ? 1 : NVB][EVG ? 1 : E];
+    if constexpr (!EVG) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
+        for (int j = 0; j < E; ++j) {
 #pragma unroll
-        for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; vv[c][j] = aw[c][j]; }
+            for (int c = 0; c < NVB; ++c) { ev[c][j] = vv[c][j]; if constexpr (!PREQ2) vv[c][j] = aw[c][j]; }
+        }
+    }
+    if constexpr (PREQ2) {
+        const cplx<T>* tw2 = twP + t;
+        cplx<T>* col2 = opaque(col);
+        Blk<T, NVB> a2[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) if (active) a2[j] = loadb<T, NVB>(col2 + NVB * TPB * j);
+        if constexpr (EVG) {
+            __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0): a is in registers before its place is overwritten
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    Blk<T, NVB> o;
+#pragma unroll
+                    for (int c = 0; c < NVB; ++c) o.c[c] = vv[c][j];
+                    storeb<T, NVB>(col2 + NVB * TPB * j, o);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const cplx<T> w = tw2[TPB * j];
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = active ? a2[j].c[c] * w : cplx<T>(0, 0);
+        }
     }
     // ---- odd bins
     F::template runN<false, NVB>(vv, lds, t, ptw);
@@ -348,8 +405,14 @@ k_col_pow2(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         for (int j = 0; j < E; ++j) {
             const cplx<T> w = tw3[TPB * j];
             Blk<T, NVB> o;
+            if constexpr (EVG) {
+                const Blk<T, NVB> e2 = loadb<T, NVB>(opaque(col) + NVB * TPB * j);
 #pragma unroll
-            for (int c = 0; c < NVB; ++c) o.c[c] = ev[c][j] + mulc(vv[c][j], w);
+                for (int c = 0; c < NVB; ++c) o.c[c] = e2.c[c] + mulc(vv[c][j], w);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) o.c[c] = ev[c][j] + mulc(vv[c][j], w);
+            }
             storeb<T, NVB>(col + NVB * TPB * j, o);
         }
     }
