@@ -49,6 +49,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured copy)
 
+# the sources that define the kernels a PMC traffic summary was taken on: profiles/*hbm_traffic.json carry the hash of
+# this set (tools/make_profile_summary.py), and a rate derived from a summary is only reported while it still matches
+KERNEL_SRC = {'pcg': ['fftconv_pow2.hip', 'fft_pow2.hpp', 'common.hpp', 'conv_plan.hpp', 'cgvec.hip', 'Makefile'],
+              'pd': ['fftconv_pow2.hip', 'fft_pow2.hpp', 'common.hpp', 'conv_plan.hpp', 'wavelet.hip', 'Makefile']}
+
+
+def kernel_src_hash(workload='pcg'):
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SRC[workload]:
+        with open(os.path.join(ROOT, 'pfb_clean_amd', 'csrc', name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -64,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--cpu-cores', type=int, default=0,
                     help='host cores for the cpu_baseline leg (0 = min(usable cores, 64): the fastest setting measured)')
+    ap.add_argument('--configs', default='auto', choices=['auto', 'all', 'none'],
+                    help="the other BASELINE configs (C1, C2, C4, C5 shard) timed in the same run and reported under "
+                         "'configs' on the JSON line; auto = all for the default one-GPU headline run")
     ap.add_argument('--force-dist', action='store_true',
                     help='run the band-sharded code path (all-reduce hook) even at world size 1')
     ap.add_argument('--cpu-worker', nargs=5, metavar=('DIR', 'BAND', 'THREADS', 'ITERS', 'SIGMAINV'),
@@ -282,14 +299,15 @@ def bench_pcg(ctx):
     if napply > 0:
         conv_ms = sum(stage_ms) / napply                              # per launch group (nb bands)
         achieved = balg_band * nb / (conv_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(n, nb, args.dtype)
+        traffic, traffic_src, traffic_commit, stale = pmc_traffic(n, nb, args.dtype)
         roofline = {
             "bound": "hbm", "kernel": "fft-convolution (row_fwd + col + row_inv)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 --pmc)",
-            "traffic_source": traffic_src,
-            "hbm_rate_from_traffic_GBs": None if traffic is None else round(traffic / (conv_ms * 1e-3) / 1e9, 1),
+            "traffic_source": traffic_src, "traffic_commit": traffic_commit, "traffic_stale": stale,
+            # bytes of the committed PMC pass over THIS run's stage times: only while the kernels are the ones it saw
+            "hbm_rate_from_traffic_GBs": None if (traffic is None or stale) else round(traffic / (conv_ms * 1e-3) / 1e9, 1),
             "alg_bytes_per_launch": balg_band * nb, "launches_timed": napply,
             "ms_per_launch": round(conv_ms, 4),
             "stage_ms": {"row_fwd": round(stage_ms[0] / napply, 4),
@@ -332,35 +350,32 @@ def bench_pcg(ctx):
     return out
 
 
-def pmc_traffic(n, nb, dtype):
-    """HBM bytes per launch of the convolution kernel group, from the committed rocprofv3
-    PMC summary of THIS workload (counters cannot be read from inside the process; they are
-    collected in separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of bench.py and
-    corrected as MI355X_MICROARCH.md prescribes).  None when no summary matches."""
+def _pmc_lookup(pattern, workload, n, nb, dtype, key):
+    """Newest committed PMC summary of this workload: (bytes, file, commit it was taken at, True when the kernel
+    sources have changed since).  Counters cannot be read from inside the process: they are collected in separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of bench.py (tools/collect_profile.sh) and corrected as
+    MI355X_MICROARCH.md prescribes; the summary records the commit and the hash of the kernel sources it saw."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic.json')), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), reverse=True):
         try:
             d = json.load(open(path))
         except Exception:
             continue
         c = d.get('config', {})
-        if c.get('workload', 'pcg') == 'pcg' and c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
-            return d.get('conv_group_hbm_bytes_per_launch'), os.path.relpath(path, ROOT)
-    return None, None
+        if c.get('workload', 'pcg') == workload and c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
+            stale = d.get('kernel_src_sha16') != kernel_src_hash(workload)
+            return d.get(key), os.path.relpath(path, ROOT), d.get('commit'), stale
+    return None, None, None, None
+
+
+def pmc_traffic(n, nb, dtype):
+    """HBM bytes per launch of the convolution kernel group (None when no summary matches)."""
+    return _pmc_lookup('*hbm_traffic.json', 'pcg', n, nb, dtype, 'conv_group_hbm_bytes_per_launch')
 
 
 def pmc_traffic_pd(n, nb, dtype):
     """The same for one primal-dual iteration (`--workload pd`): profiles/*pd_hbm_traffic.json."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pd_hbm_traffic.json')), reverse=True):
-        try:
-            d = json.load(open(path))
-        except Exception:
-            continue
-        c = d.get('config', {})
-        if c.get('workload') == 'pd' and c.get('size') == n and c.get('bands') == nb and c.get('dtype') == dtype:
-            return d.get('hbm_bytes_per_iteration'), os.path.relpath(path, ROOT)
-    return None, None
+    return _pmc_lookup('*pd_hbm_traffic.json', 'pd', n, nb, dtype, 'hbm_bytes_per_iteration')
 
 
 # ------------------------------------------------------------------------------ CPU leg
@@ -537,13 +552,13 @@ def bench_pd(ctx):
     balg = s * nband * ((N + coef) + (coef + N) + 4 * coef + (2 * N + 2 * (2 * n) * (Q // 2 + 1)) + 3 * N + 4 * N) \
         + s * coef
     achieved = balg / elapsed * args.steps / 1e9
-    traffic, traffic_src = pmc_traffic_pd(n, nband, args.dtype)
+    traffic, traffic_src, traffic_commit, stale = pmc_traffic_pd(n, nband, args.dtype)
     roofline = {"bound": "hbm", "kernel": "primal-dual iteration (psi^H, dual update, psi, PSF conv, primal update)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per iteration (FETCH_SIZE x2 + WRITE_SIZE over the iteration's kernels, rocprofv3 --pmc)",
-                "traffic_source": traffic_src,
-                "hbm_rate_from_traffic_GBs": round(traffic / elapsed * args.steps / 1e9, 1) if traffic else None,
+                "traffic_source": traffic_src, "traffic_commit": traffic_commit, "traffic_stale": stale,
+                "hbm_rate_from_traffic_GBs": round(traffic / elapsed * args.steps / 1e9, 1) if (traffic and not stale) else None,
                 "alg_bytes_per_iteration": balg, "ms_per_iteration": round(1e3 * elapsed / args.steps, 4),
                 "timing": "wall clock of the timed region / steps (the iteration is several launches; the host "
                           "reads three scalars per iteration)"}

@@ -48,6 +48,7 @@ extern "C" {
 #define PFB_ERR_HIP         -3   /* a HIP runtime call failed                            */
 #define PFB_ERR_NONFINITE   -4   /* NaN/Inf met where the reference drops into pdb       */
 #define PFB_ERR_ALLOC       -5   /* device allocation for a plan failed                  */
+#define PFB_ERR_COMM        -6   /* the band-shard exchange failed, was aborted or timed out */
 
 /* pcg exit status (written to pfb_pcg_result.status) */
 #define PFB_PCG_CONVERGED     0  /* "Success, converged after k iterations" pcg.py:131-132 */
@@ -184,6 +185,16 @@ int pfb_axpby(int dtype, double a, const void* x, double b, void* y, size_t n,
  * allreduce: optional hook for band-sharded multi-GPU solves -- called on `stream`
  * order with a device buffer of `count` doubles that must be summed in place over
  * all ranks (RCCL); NULL for single-GPU.
+ * Failure protocol (the reference's sums run over all bands in one process, pfb/opt/pcg.py:90-107, and cannot
+ * lose a participant; a sharded solve can).  The same function doubles as the health interface of the exchange:
+ *   count  > 0   the exchange itself; non-zero return = it could not be issued
+ *   count == 0   PROBE (dev_buf NULL): non-zero = the exchange has failed asynchronously (a peer died, the
+ *                communicator was aborted); called by the solver while it waits for the device
+ *   count  < 0   ABORT (dev_buf NULL): tear the exchange down so that neither this rank nor its peers stay blocked
+ *                in a collective; called once before the solver gives up
+ * A solver with a hook never waits for the device unboundedly: it polls, probes, and after PFB_COMM_TIMEOUT_S
+ * seconds (environment, default 600) without progress aborts the exchange.  In all three cases pfb_pcg_solve
+ * returns PFB_ERR_COMM; the caller's buffers then hold no result and the process should exit non-zero.
  */
 typedef int (*pfb_allreduce_fn)(void* ctx, double* dev_buf, int count, void* stream);
 
@@ -232,7 +243,13 @@ int pfb_comm_unique_id(void* id128);
 int pfb_comm_init(int rank, int nranks, const void* id128, pfb_comm** out);
 int pfb_comm_destroy(pfb_comm* comm);
 int pfb_comm_info(const pfb_comm* comm, int* rank, int* nranks, int* device, int* rccl_version);
-int pfb_comm_allreduce(void* comm, double* dev_buf, int count, void* stream);
+int pfb_comm_allreduce(void* comm, double* dev_buf, int count, void* stream);   /* incl. the probe / abort protocol */
+/* asynchronous state of the communicator (ncclCommGetAsyncError): PFB_OK, or PFB_ERR_COMM once a collective on it
+ * has failed or it was aborted */
+int pfb_comm_check(pfb_comm* comm);
+/* ncclCommAbort: frees the communicator's resources and makes every collective still queued on it, here AND on the
+ * peers, complete with an error instead of blocking; the handle stays valid for pfb_comm_destroy only */
+int pfb_comm_abort(pfb_comm* comm);
 
 /* ----------------------------------------------------------- wavelets / prox / PD
  * Replaces pfb/wavelets/wavelets.py:175-213 (dwt2d), :261-315 (idwt2d) and

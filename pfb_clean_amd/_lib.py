@@ -14,19 +14,26 @@ LIB_PATH = os.environ.get('PFB_HIP_LIB') or os.path.join(_HERE, 'libpfb_hip.so')
 PFB_F32, PFB_F64 = 0, 1
 PFB_OK = 0
 ERRORS = {-1: 'invalid argument', -2: 'unsupported size/dtype', -3: 'HIP runtime error',
-          -4: 'non-finite value', -5: 'device allocation failed'}
+          -4: 'non-finite value', -5: 'device allocation failed', -6: 'band-shard exchange failed'}
 PCG_STATUS = {0: 'converged', 1: 'maxit', 2: 'zero-residual', 3: 'breakdown'}
 REDUCE_WS_DOUBLES = 8192
 
 
 PFB_ERR_INVALID = -1
 PFB_ERR_UNSUPPORTED = -2
+PFB_ERR_ALLOC = -5
+PFB_ERR_COMM = -6
 
 
 class PfbHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libpfb_hip: {ERRORS.get(code, code)}: {msg}")
         self.code = code
+
+
+class PfbCommError(PfbHipError):
+    """PFB_ERR_COMM: the band-shard exchange of a distributed solve failed, was aborted or timed out.  The exchange has
+    been torn down; this rank holds no result and should exit non-zero (its peers get the same error)."""
 
 
 class PcgResult(C.Structure):
@@ -65,6 +72,8 @@ SIGNATURES = {
     'pfb_comm_destroy': (_i, [_vp]),
     'pfb_comm_info': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'pfb_comm_allreduce': (_i, [_vp, _vp, _i, _vp]),
+    'pfb_comm_check': (_i, [_vp]),
+    'pfb_comm_abort': (_i, [_vp]),
     'pfb_psi_plan_create': (_i, [_i, _i, _i, _i, C.POINTER(_i), C.POINTER(_d), _i, _i,
                                  C.POINTER(_vp)]),
     'pfb_psi_plan_destroy': (_i, [_vp]),
@@ -110,5 +119,5 @@ def load():
 def check(code):
     if code != PFB_OK:
         msg = load().pfb_last_error()
-        raise PfbHipError(code, msg.decode() if msg else '')
+        raise (PfbCommError if code == PFB_ERR_COMM else PfbHipError)(code, msg.decode() if msg else '')
     return code

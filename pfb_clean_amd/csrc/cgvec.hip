@@ -10,6 +10,8 @@
 // memory (alpha, beta are read by the kernels from there), the p.Ap product comes
 // fused out of the convolution epilogue (fftconv*.hip).
 #include "conv_plan.hpp"
+#include <chrono>
+#include <unistd.h>
 #include <cstring>
 #include <cstdlib>
 
@@ -612,18 +614,56 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     T* rnew = ralt;
 
     memset(res, 0, sizeof(*res));
+    if (allreduce) set_error("%s", "");        // comm_fail() quotes the hook's message: no stale text from an earlier call
     PFB_HIP_CHECK(hipMemsetAsync(S, 0, sizeof(double) * 64, st));
 
+    // ---- the exchange can lose a participant (include/pfb_hip.h, "Failure protocol"): with a hook the solver never
+    // waits for the device unboundedly -- it polls an event, probes the exchange (count = 0) and gives up after
+    // PFB_COMM_TIMEOUT_S seconds, aborting the exchange (count < 0) so that no rank stays blocked in a collective
+    struct WaitEvent {
+        hipEvent_t ev = nullptr;
+        ~WaitEvent() { if (ev) (void)hipEventDestroy(ev); }
+    } wev;
+    double comm_timeout = 600.0;
+    if (allreduce) {
+        if (const char* e = getenv("PFB_COMM_TIMEOUT_S")) { const double v = atof(e); if (v > 0) comm_timeout = v; }
+        PFB_HIP_CHECK(hipEventCreateWithFlags(&wev.ev, hipEventDisableTiming));
+    }
+    auto comm_fail = [&](const char* what) -> int {
+        char msg[384];
+        snprintf(msg, sizeof(msg), "%s", pfb_last_error());      // the hook's own message, if it left one
+        (void)allreduce(actx, nullptr, -1, (void*)st);            // abort: peers blocked in the collective are released
+        set_error("pcg: %s%s%s -- exchange aborted, this rank's result is void", what, msg[0] ? ": " : "", msg);
+        return PFB_ERR_COMM;
+    };
     auto reduce_hook = [&](int first, int count) -> int {
         if (!allreduce) return PFB_OK;
-        int e2 = allreduce(actx, S + first, count, (void*)st);
-        if (e2 != 0) { set_error("pcg: allreduce hook failed (%d)", e2); return PFB_ERR_HIP; }
+        if (allreduce(actx, S + first, count, (void*)st) != 0) return comm_fail("the all-reduce hook failed");
         return PFB_OK;
+    };
+    auto wait_stream = [&]() -> int {
+        if (!allreduce) { PFB_HIP_CHECK(hipStreamSynchronize(st)); return PFB_OK; }
+        PFB_HIP_CHECK(hipEventRecord(wev.ev, st));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(wev.ev);
+            if (q == hipSuccess) return PFB_OK;
+            if (q != hipErrorNotReady) { set_error("pcg: hipEventQuery -> %s", hipGetErrorString(q)); return PFB_ERR_HIP; }
+            if (spins < 4096) continue;                           // a look normally returns within tens of microseconds
+            if (allreduce(actx, nullptr, 0, (void*)st) != 0) return comm_fail("the exchange reported a failure");
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > comm_timeout) {
+                char what[128];
+                snprintf(what, sizeof(what), "no progress on the solver's stream for %.0f s (PFB_COMM_TIMEOUT_S)", el);
+                set_error("%s", "");
+                return comm_fail(what);
+            }
+            usleep(el < 0.01 ? 20 : 500);
+        }
     };
     auto fetch = [&]() -> int {
         PFB_HIP_CHECK(hipMemcpyAsync(h, S, sizeof(double) * S_NSCALAR, hipMemcpyDeviceToHost, st));
-        PFB_HIP_CHECK(hipStreamSynchronize(st));
-        return PFB_OK;
+        return wait_stream();
     };
     int err;
 
@@ -642,8 +682,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         res->eps = 1.0;
         res->rnorm = h[S_RHO];
         if (r_out) PFB_HIP_CHECK(hipMemcpyAsync(r_out, rcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
-        PFB_HIP_CHECK(hipStreamSynchronize(st));
-        return PFB_OK;
+        return wait_stream();
     }
 
     int k = 0;
@@ -734,6 +773,19 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
                 PFB_HIP_CHECK(hipEventRecord(plan->pcg_ev[slot], st));
                 stale_h = true;
                 if (have_prev) {
+                    if (allreduce) {            // bounded: the same poll / probe / timeout as every other look
+                        const auto t0 = std::chrono::steady_clock::now();
+                        for (long spins = 0;; ++spins) {
+                            const hipError_t q = hipEventQuery(plan->pcg_ev[slot ^ 1]);
+                            if (q == hipSuccess) break;
+                            if (q != hipErrorNotReady) { set_error("pcg: hipEventQuery -> %s", hipGetErrorString(q)); return PFB_ERR_HIP; }
+                            if (spins < 4096) continue;
+                            if (allreduce(actx, nullptr, 0, (void*)st) != 0) return comm_fail("the exchange reported a failure");
+                            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                            if (el > comm_timeout) { set_error("%s", ""); return comm_fail("no progress on the solver's stream (PFB_COMM_TIMEOUT_S)"); }
+                            usleep(el < 0.01 ? 20 : 500);
+                        }
+                    } else
                     PFB_HIP_CHECK(hipEventSynchronize(plan->pcg_ev[slot ^ 1]));
                     const double* hp = plan->pcg_pin + (size_t)(slot ^ 1) * S_NSCALAR;
                     if (hp[S_DEAD] != 0.0) { status = PFB_PCG_BREAKDOWN; break; }
@@ -818,7 +870,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
     res->rnorm = rho;
     if (xcur != (T*)x) PFB_HIP_CHECK(hipMemcpyAsync(x, xcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
     if (r_out) PFB_HIP_CHECK(hipMemcpyAsync(r_out, rcur, n * sizeof(T), hipMemcpyDeviceToDevice, st));
-    PFB_HIP_CHECK(hipStreamSynchronize(st));
+    if ((err = wait_stream()) != PFB_OK) return err;
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }

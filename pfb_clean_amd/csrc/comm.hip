@@ -28,6 +28,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;   // optional (failure handling)
+    decltype(&ncclCommAbort) CommAbort = nullptr;                   // optional
     char path[512] = {0};
 };
 Rccl g_rccl;
@@ -52,6 +54,8 @@ int bind_rccl(const char* path_hint) {
     if (!r.N) { set_error("comm: %s lacks nccl" #N, how); dlclose(h); return PFB_ERR_UNSUPPORTED; }
     SYM(GetVersion) SYM(GetUniqueId) SYM(CommInitRank) SYM(CommDestroy) SYM(AllReduce) SYM(GetErrorString)
 #undef SYM
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
     snprintf(r.path, sizeof(r.path), "%s", how);
     g_rccl = r;
     return PFB_OK;
@@ -72,6 +76,7 @@ int bind_rccl(const char* path_hint) {
 struct pfb_comm {
     ncclComm_t comm;
     int rank, nranks, device;
+    int dead;                // aborted or failed: nothing may be enqueued on it any more
 };
 
 using namespace pfb;
@@ -103,14 +108,14 @@ int pfb_comm_init(int rank, int nranks, const void* id128, pfb_comm** out) {
     PFB_HIP_CHECK(hipGetDevice(&dev));               // the communicator binds to the caller's current device
     ncclComm_t c = nullptr;
     PFB_NCCL_CHECK(g_rccl.CommInitRank(&c, nranks, id, rank));
-    pfb_comm* p = new pfb_comm{c, rank, nranks, dev};
+    pfb_comm* p = new pfb_comm{c, rank, nranks, dev, 0};
     *out = p;
     return PFB_OK;
 }
 
 int pfb_comm_destroy(pfb_comm* c) {
     if (!c) return PFB_OK;
-    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->comm && !c->dead && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);   // (an aborted communicator is already freed)
     delete c;
     return PFB_OK;
 }
@@ -124,11 +129,43 @@ int pfb_comm_info(const pfb_comm* c, int* rank, int* nranks, int* device, int* r
     return PFB_OK;
 }
 
-// a pfb_allreduce_fn (ctx = the pfb_comm*): sums `count` doubles in place over the ranks, ordered on `stream`
+int pfb_comm_check(pfb_comm* c) {
+    PFB_REQUIRE(c, PFB_ERR_INVALID, "comm_check: null communicator");
+    PFB_REQUIRE(!c->dead, PFB_ERR_COMM, "comm: the communicator of rank %d was aborted", c->rank);
+    if (!g_rccl.CommGetAsyncError) return PFB_OK;           // this RCCL cannot tell: the solver's timeout still holds
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t q = g_rccl.CommGetAsyncError(c->comm, &st);
+    if (q == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return PFB_OK;
+    set_error("comm: asynchronous error on rank %d of %d: %s", c->rank, c->nranks,
+              g_rccl.GetErrorString(q != ncclSuccess ? q : st));
+    return PFB_ERR_COMM;
+}
+
+int pfb_comm_abort(pfb_comm* c) {
+    PFB_REQUIRE(c, PFB_ERR_INVALID, "comm_abort: null communicator");
+    if (c->dead) return PFB_OK;
+    c->dead = 1;
+    if (c->comm && g_rccl.CommAbort) {
+        g_rccl.CommAbort(c->comm);           // peers' pending collectives on this communicator now fail instead of waiting
+        c->comm = nullptr;
+    }
+    return PFB_OK;
+}
+
+// a pfb_allreduce_fn (ctx = the pfb_comm*): sums `count` doubles in place over the ranks, ordered on `stream`;
+// count == 0: probe, count < 0: abort (include/pfb_hip.h, "Failure protocol")
 int pfb_comm_allreduce(void* ctx, double* dev_buf, int count, void* stream) {
     pfb_comm* c = static_cast<pfb_comm*>(ctx);
-    PFB_REQUIRE(c && c->comm && dev_buf && count > 0, PFB_ERR_INVALID, "comm_allreduce: bad argument");
-    PFB_NCCL_CHECK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
+    PFB_REQUIRE(c, PFB_ERR_INVALID, "comm_allreduce: null communicator");
+    if (count == 0) return pfb_comm_check(c);
+    if (count < 0) return pfb_comm_abort(c);
+    PFB_REQUIRE(!c->dead && c->comm, PFB_ERR_COMM, "comm_allreduce: the communicator of rank %d was aborted", c->rank);
+    PFB_REQUIRE(dev_buf, PFB_ERR_INVALID, "comm_allreduce: null buffer");
+    const ncclResult_t r = g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream);
+    if (r != ncclSuccess) {
+        set_error("comm_allreduce: rank %d of %d: %s", c->rank, c->nranks, g_rccl.GetErrorString(r));
+        return PFB_ERR_COMM;
+    }
     return PFB_OK;
 }
 

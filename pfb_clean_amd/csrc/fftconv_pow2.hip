@@ -143,6 +143,7 @@ constexpr int row_groups() {
 }
 template <int H, int E>
 constexpr int col_groups() { return (H / E) >= 256 ? 1 : 256 / (H / E); }
+constexpr int ECOLX = 8;      // elements per thread of the two-level column kernel's sub-transforms (k_col_pow2x)
 
 // NVB adjacent complex values as one aligned 16-byte access
 template <typename T, int NVB> struct alignas(16) Blk { cplx<T> c[NVB]; };
@@ -177,6 +178,13 @@ __device__ __forceinline__ P* opaque(P* p) {
     return p;
 }
 
+// LAUNDER_EARLY: see the comment at the row kernels -- values derived from the thread index are loop invariant, and
+// the optimiser keeps whatever it can compute from them live across a persistent kernel's whole loop
+__device__ __forceinline__ int launder(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // XCD-aware row-group order of the plain row kernels.  A workgroup of G rows touches T in G x 16-byte pieces; 8 rows
 // make a 128-byte line.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so the
 // SH = 8 / G row groups of one line are given to blocks b, b + 8, .. b + 8 (SH - 1): their pieces meet in ONE L2 and
@@ -209,12 +217,19 @@ __host__ __device__ inline void block_of_bin(int v, int L, int nvb, int* blk, in
     *c = m % nvb;
 }
 inline int fast_nblocks(int L, int nvb) { return (L + nvb) / nvb + L / nvb; }
+// element offset of psfhat[u][v(blk, c)] inside a band of psf_l (H = nx = P / 2 rows per parity).
+//   four = 0: parity-major  psf_l[blk][u & 1][u >> 1][c]     (k_col_pow2, k_col_pow2p)
+//   four = 1: class-major   psf_l[blk][u & 3][u >> 2][c]     (k_col_pow2x: the two-level column transform)
+__host__ __device__ inline size_t psf_off(int blk, int u, int c, int H, int nvb, int four) {
+    return four ? (((size_t)blk * 4 + (u & 3)) * (size_t)(H / 2) + (u >> 2)) * nvb + c
+                : (((size_t)blk * 2 + (u & 1)) * (size_t)H + (u >> 1)) * nvb + c;
+}
 
 #if PFB_POW2_REST
 // psf_l[band][blk][pu][mu][c] = psfhat[band][2 mu + pu][v]
 template <typename T>
 __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>* __restrict__ psf_l,
-                                    int P, int nv, int L, int nvb, size_t psf_band) {
+                                    int P, int nv, int L, int nvb, size_t psf_band, int four) {
     // tile transpose through LDS: block handles 32 u x 32 v
     __shared__ cplx<T> tile[32][33];
     const int band = blockIdx.z;
@@ -231,7 +246,7 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
         if (u < P && v < nv) {
             int blk, c;
             block_of_bin(v, L, nvb, &blk, &c);
-            psf_l[(size_t)band * psf_band + (((size_t)blk * 2 + (u & 1)) * H + (u >> 1)) * nvb + c] = tile[tx][r];
+            psf_l[(size_t)band * psf_band + psf_off(blk, u, c, H, nvb, four)] = tile[tx][r];
         }
     }
 }
@@ -239,7 +254,7 @@ __global__ void k_relayout_psf_pow2(const cplx<T>* __restrict__ psfhat, cplx<T>*
 // psfhat[band][u][v] = psf_l[band][blk][u & 1][u >> 1][c]: the reference's layout back out of the plan's
 template <typename T>
 __global__ void k_unrelayout_psf_pow2(const cplx<T>* __restrict__ psf_l, cplx<T>* __restrict__ psfhat,
-                                      int P, int nv, int L, int nvb, size_t psf_band) {
+                                      int P, int nv, int L, int nvb, size_t psf_band, int four) {
     __shared__ cplx<T> tile[32][33];
     const int band = blockIdx.z;
     const int u0 = blockIdx.y * 32, v0 = blockIdx.x * 32;
@@ -250,7 +265,7 @@ __global__ void k_unrelayout_psf_pow2(const cplx<T>* __restrict__ psf_l, cplx<T>
         if (u < P && v < nv) {
             int blk, c;
             block_of_bin(v, L, nvb, &blk, &c);
-            tile[tx][r] = psf_l[(size_t)band * psf_band + (((size_t)blk * 2 + (u & 1)) * H + (u >> 1)) * nvb + c];
+            tile[tx][r] = psf_l[(size_t)band * psf_band + psf_off(blk, u, c, H, nvb, four)];
         }
     }
     __syncthreads();
@@ -590,6 +605,252 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     }
 }
 
+// ------------------------------------------- column, two-level (four residue classes), persistent
+// Long columns (H = 8192: one 16-byte block of a column is 128 KB, the whole register file of a CU holds four of them)
+// do not fit the kernel above: its exchange buffers fill the LDS, the tables do not fit next to them, 1024 threads cap
+// the registers at 128 -- the plain kernel then runs one workgroup per CU barrier to barrier with every load latency
+// exposed (1.1 TB/s of traffic at 8192^2 fp32 against 5.4 TB/s at 4096^2) and spills.  Here the padded length-4 HS
+// transform (H = 2 HS samples, zero beyond) is split by the residue of the output bin modulo 4:
+//     X[4m + r] = FFT_HS( (a[n] + (-i)^r a[n + HS]) w_P^(r n) )[m]                      r = 0..3,  n, m < HS
+//     b[n + s HS] = sum_r  i^(s r) conj(w_P^(r n)) IFFT_HS( X[4 . + r] psf[4 . + r] )[n]        s = 0, 1
+// i.e. FOUR rounds of (combine, FFT_HS, multiply, IFFT_HS, accumulate) on the persistent, spill-free HS-point tile:
+// half the threads, half the exchange buffer, and the loads ride inside the transforms (RegFft pass hooks), in issue
+// order per trip
+//     round r:      IFFT passes  <- psf slice of the NEXT round (last round: class 0 of the next item)
+//     rounds 1, 3:  FFT passes   <- upper / lower half of the next item's column (into the registers a just left)
+// Rounds run in the order 0, 2, 1, 3: after round 0 both output halves are the same array, two accumulators exist from
+// the end of the second round only -- and the upper one lives in the LDS (`park`: the exchange buffer is half the
+// usual size), so that at most FIVE arrays of E blocks are live in registers at any time (the 4096-point persistent
+// kernel: five).  The twiddles w_P^n, n = t + TPB j, are w_P^t (LDS table of TPB entries) times the compile-time
+// constants exp(-2 pi i j / 4E).  The PSF spectrum is stored class-major for this kernel (psf_l[blk][r][m][c] =
+// psfhat[4 m + r], see psf_off), so that every slice is a contiguous 16-byte-per-lane stream.
+template <typename T>
+__device__ __forceinline__ cplx<T> root32(int k) {              // exp(-2 pi i k / 32); folds to constants for constant k
+    constexpr T C[9] = {T(1), T(0.98078528040323044912618223613423903697L), T(0.92387953251128675612818318939678828682L),
+                        T(0.83146961230254523707878837761790575673L), T(0.70710678118654752440084436210484903928L),
+                        T(0.55557023301960222474283081394853287438L), T(0.38268343236508977172845998403039886676L),
+                        T(0.19509032201612826784828486847702224093L), T(0)};
+    auto cs = [&](int q) -> T {                                 // cos(2 pi q / 32)
+        q &= 31;
+        return q <= 8 ? C[q] : q <= 16 ? -C[16 - q] : q <= 24 ? -C[q - 16] : C[32 - q];
+    };
+    return cplx<T>(cs(k), -cs(k - 8));
+}
+
+template <typename T, int H, int E>
+struct ColX {
+    static constexpr int HS = H / 2;
+    using F = RegFft<T, HS, E, false, 0, true>;
+    static constexpr int NVB = FastCfg<T>::NVB;
+    static constexpr int GC = col_groups<HS, E>();
+    static constexpr int NT = GC * F::TPB;
+    static constexpr int XB = NVB * F::LDS_ELEMS;
+    static constexpr int PTWP = (F::PTWC + 1) & ~1;
+    static constexpr size_t LDS = sizeof(cplx<T>) * ((size_t)PTWP + F::TPB + (size_t)GC * XB + (size_t)NT * E * NVB);
+    static_assert(E == 8, "root32: the twiddle constants are the 4E-th roots of unity");
+};
+
+template <typename T, int H, int E, bool NT = false>
+__global__ void __launch_bounds__((ColX<T, H, E>::NT), 2)
+k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
+            const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
+            int nblk, int nitems, size_t T_band, size_t psf_band, int band0, int bstep) {
+    using X = ColX<T, H, E>;
+    using F = typename X::F;
+    constexpr int NVB = X::NVB, HS = X::HS, TPB = F::TPB, GC = X::GC, NP = F::NPASS, NTH = X::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
+    cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
+    cplx<T>* ltx = ltw + X::PTWP;                               // w_P^n, n < TPB
+    cplx<T>* lds = ltx + TPB + (size_t)g * X::XB;
+    Blk<T, NVB>* park = reinterpret_cast<Blk<T, NVB>*>(ltx + TPB + (size_t)GC * X::XB) + threadIdx.x;   // [j][thread]
+    const int stride = gridDim.x * GC;
+    const int niter = (nitems + stride - 1) / stride;           // same for every workgroup
+
+    for (int k = threadIdx.x; k < F::PTWC; k += NTH) ltw[k] = ptwc[k];
+    for (int k = threadIdx.x; k < TPB; k += NTH) ltx[k] = twP[k];
+
+    auto col_of = [&](int item) -> cplx<T>* {
+        const int bl = item / nblk, blk = item - bl * nblk;
+        return Tw + (size_t)(band0 + bstep * bl) * T_band + ((size_t)blk * H + t) * NVB;
+    };
+    auto psf_of = [&](int item) -> const cplx<T>* {             // class 0 of the item; class r: + r HS NVB
+        const int bl = item / nblk, blk = item - bl * nblk;
+        return psf_l + (size_t)(band0 + bstep * bl) * psf_band + ((size_t)blk * 2 * H + t) * NVB;
+    };
+    auto ldq = [&](const cplx<T>* p) __attribute__((always_inline)) { return NT ? loadb_nt<T, NVB>(p) : loadb<T, NVB>(p); };
+
+    int item = blockIdx.x * GC + g;
+    Blk<T, NVB> al[E], ah[E], q[E];
+    {
+        const bool act = item < nitems;
+        const cplx<T>* c0 = col_of(act ? item : 0);
+        const cplx<T>* p0 = psf_of(act ? item : 0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            al[j] = loadb<T, NVB>(c0 + NVB * TPB * j);
+            ah[j] = loadb<T, NVB>(c0 + NVB * (HS + TPB * j));
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) q[j] = ldq(p0 + NVB * TPB * j);
+    }
+    __syncthreads();                                            // tables visible
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it, item += stride) {
+        const bool active = item < nitems;
+        cplx<T>* col = col_of(active ? item : 0);
+        const cplx<T>* ps = psf_of(active ? item : 0);
+        const int nxt = item + stride;
+        const bool nact = nxt < nitems;                         // a trip past the end re-reads a valid block and drops it
+        const cplx<T>* cn = col_of(nact ? nxt : (active ? item : 0));
+        const cplx<T>* psn = psf_of(nact ? nxt : (active ? item : 0));
+        cplx<T> vv[NVB][E], ol[NVB][E];
+        // w_P^t, laundered at every use: t and the table are loop invariant, and the optimiser would otherwise keep
+        // w, w^2, w^3 of all E samples live across the whole item loop
+        auto wt = [&]() __attribute__((always_inline)) { return ltx[launder(t)]; };
+        auto mulq = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
+            }
+        };
+        auto ifft_q = [&](const cplx<T>* pq) __attribute__((always_inline)) {   // inverse transform; its passes request the slice at pq
+            F::template runN<true, NVB>(vv, lds, t, ltw, [&](auto k) {
+                constexpr int K = decltype(k)::value;
+#pragma unroll
+                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = ldq(pq + NVB * TPB * j);
+            });
+        };
+        STAMP(1, it, 0);
+        // ---- round r = 0:  a_lo + a_hi
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = al[j].c[c] + ah[j].c[c];
+        }
+        F::template runN<false, NVB>(vv, lds, t, ltw);
+        STAMP(1, it, 1);
+        mulq();
+        ifft_q(ps + (size_t)2 * HS * NVB);
+        STAMP(1, it, 2);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) ol[c][j] = vv[c][j];
+        }
+        // ---- round r = 2:  (a_lo - a_hi) w^2n
+        {
+            const cplx<T> w1 = wt(), wt2 = w1 * w1;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> w2 = wt2 * root32<T>(2 * j);
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) vv[c][j] = (al[j].c[c] - ah[j].c[c]) * w2;
+            }
+        }
+        STAMP(1, it, 3);
+        F::template runN<false, NVB>(vv, lds, t, ltw);
+        STAMP(1, it, 4);
+        mulq();
+        ifft_q(ps + (size_t)1 * HS * NVB);
+        STAMP(1, it, 5);
+        {
+            const cplx<T> w1 = wt(), wt2 = w1 * w1;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> w2 = wt2 * root32<T>(2 * j);
+                Blk<T, NVB> hi;
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) {
+                    const cplx<T> u = mulc(vv[c][j], w2);
+                    hi.c[c] = ol[c][j] - u;
+                    ol[c][j] = ol[c][j] + u;
+                }
+                park[j * NTH] = hi;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- round r = 1:  (a_lo - i a_hi) w^n.  The input of round 3, (a_lo + i a_hi) w^3n, is formed here as well and
+        // parked in a_lo's registers: the column dies one round early and a_hi's registers take the upper half of the
+        // next item's column during this round's forward transform
+        {
+            const cplx<T> w1t = wt(), w3t = w1t * (w1t * w1t);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> w1 = w1t * root32<T>(j), w3 = w3t * root32<T>(3 * j);
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) {
+                    const cplx<T> lo = al[j].c[c], hi = ah[j].c[c];
+                    vv[c][j] = addrot<false>(lo, hi) * w1;
+                    al[j].c[c] = addrot<true>(lo, hi) * w3;
+                }
+                __builtin_amdgcn_sched_barrier(0);          // one sample at a time: the temporaries of all E at once spill
+            }
+        }
+        STAMP(1, it, 6);
+        F::template runN<false, NVB>(vv, lds, t, ltw, [&](auto k) {
+            constexpr int K = decltype(k)::value;
+#pragma unroll
+            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) ah[j] = loadb<T, NVB>(cn + NVB * (HS + TPB * j));
+        });
+        STAMP(1, it, 7);
+        mulq();
+        ifft_q(ps + (size_t)3 * HS * NVB);
+        STAMP(1, it, 8);
+        {
+            const cplx<T> w1t = wt();
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> w1 = w1t * root32<T>(j);
+                Blk<T, NVB> hi = park[j * NTH];
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) {
+                    const cplx<T> u = mulc(vv[c][j], w1);
+                    ol[c][j] = ol[c][j] + u;
+                    hi.c[c] = addrot<true>(hi.c[c], u);              // + i u
+                }
+                park[j * NTH] = hi;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- round r = 3: its input leaves a_lo's registers, which take the lower half of the next item's column
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+#pragma unroll
+            for (int c = 0; c < NVB; ++c) vv[c][j] = al[j].c[c];
+        }
+        STAMP(1, it, 9);
+        F::template runN<false, NVB>(vv, lds, t, ltw, [&](auto k) {
+            constexpr int K = decltype(k)::value;
+#pragma unroll
+            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) al[j] = loadb<T, NVB>(cn + NVB * TPB * j);
+        });
+        STAMP(1, it, 10);
+        mulq();
+        ifft_q(psn);
+        STAMP(1, it, 11);
+        if (active) {
+            const cplx<T> w1t = wt(), w3t = w1t * (w1t * w1t);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const cplx<T> w3 = w3t * root32<T>(3 * j);
+                const Blk<T, NVB> hi = park[j * NTH];
+                Blk<T, NVB> o0, o1;
+#pragma unroll
+                for (int c = 0; c < NVB; ++c) {
+                    const cplx<T> u = mulc(vv[c][j], w3);
+                    o0.c[c] = ol[c][j] + u;
+                    o1.c[c] = addrot<false>(hi.c[c], u);         // - i u
+                }
+                storeb<T, NVB>(col + NVB * TPB * j, o0);
+                storeb<T, NVB>(col + NVB * (HS + TPB * j), o1);
+            }
+        }
+        STAMP(1, it, 12);
+    }
+}
+
 // ------------------------------------------------- column, forward only: the PSFHAT producer
 // psfhat = r2c(ifftshift(psf)) (gridder.py:712-714) on the fast path's own kernels.  The (P, Q) = (2 nx, 2 ny)
 // shifted PSF s is cut into its four (nx, ny) quadrants s_ab (a: top / bottom, b: left / right); the PRUNED
@@ -603,7 +864,7 @@ template <typename T, int H, int E>
 __global__ void __launch_bounds__((col_groups<H, E>() * (H / E)), (E >= 16 ? 2 : FastCfg<T>::WCOL))
 k_col_fwd_pow2(const cplx<T>* __restrict__ Tq, cplx<T>* __restrict__ psf_b,
                const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptw,
-               int nblk, int nbe, size_t T_band) {
+               int nblk, int nbe, size_t T_band, int four) {
     using F = RegFft<T, H, E>;
     constexpr int TPB = F::TPB;
     constexpr int NVB = FastCfg<T>::NVB;
@@ -633,8 +894,7 @@ k_col_fwd_pow2(const cplx<T>* __restrict__ Tq, cplx<T>* __restrict__ psf_b,
             }
         }
     }
-    cplx<T>* pe = psf_b + (b * (2 * (size_t)H) + t) * NVB;
-    cplx<T>* po = pe + (size_t)H * NVB;
+    // psfhat[2 k + pu] of this block: parity-major or class-major (psf_off), k = t + TPB j
     F::template runN<false, NVB>(ve, lds, t, ptw);
     if (active) {
 #pragma unroll
@@ -642,7 +902,7 @@ k_col_fwd_pow2(const cplx<T>* __restrict__ Tq, cplx<T>* __restrict__ psf_b,
             Blk<T, NVB> o;
 #pragma unroll
             for (int c = 0; c < NVB; ++c) o.c[c] = ve[c][j];
-            storeb<T, NVB>(pe + NVB * TPB * j, o);
+            storeb<T, NVB>(psf_b + psf_off((int)b, 2 * (t + TPB * j), 0, H, NVB, four), o);
         }
     }
     F::template runN<false, NVB>(vo, lds, t, ptw);
@@ -652,7 +912,7 @@ k_col_fwd_pow2(const cplx<T>* __restrict__ Tq, cplx<T>* __restrict__ psf_b,
             Blk<T, NVB> o;
 #pragma unroll
             for (int c = 0; c < NVB; ++c) o.c[c] = vo[c][j];
-            storeb<T, NVB>(po + NVB * TPB * j, o);
+            storeb<T, NVB>(psf_b + psf_off((int)b, 2 * (t + TPB * j) + 1, 0, H, NVB, four), o);
         }
     }
 }
@@ -797,10 +1057,7 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
 // scratch reloads are vector-memory operations, and one of them inside an FFT (in-order
 // vmcnt) waits for the prefetch it was supposed to overlap with.  Laundering the index at
 // the top of each iteration makes the (cheap) address arithmetic part of the loop body.
-__device__ __forceinline__ int launder(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
+// (launder() itself is defined near the top of the file)
 
 // ------------------------------------------------- row forward, persistent + pipelined
 // Same recipe as k_row_inv_pow2p below (read its comment first): one resident 1024-thread
@@ -1806,6 +2063,8 @@ struct FastTables {            // device tables owned by the plan (stored behind
     int fwd_persistent;        // PFB_FWD_PERSIST (default 1): persistent pipelined forward row kernel where it fits
     int inv_persistent;        // PFB_INV_PERSIST (default 1): persistent pipelined inverse row kernel where it fits
     int num_cu;
+    void* ptwc_col_x;          // compact pass table of its HS = nx / 2 point sub-transform
+    int col_x;                 // two-level column kernel k_col_pow2x + class-major psf_l (default: nx = 8192; PFB_COL_X=0/1 forces)
 };
 // the column object's entry points (defined under PFB_POW2_COL below)
 int pow2_col_set_attr(int dtype, int H);
@@ -1882,6 +2141,7 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     switch (H) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, ecol<T, NN>()>(&ft->ptw_col);                          \
         if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, ecol<T, NN>()>(&ft->ptwc_col);             \
+        if (rc == PFB_OK && NN >= 2048) rc = prep_ptw_compact<T, (NN >= 2048 ? NN / 2 : 1024), ECOLX>(&ft->ptwc_col_x); \
         if (rc == PFB_OK) rc = pow2_col_set_attr(p->dtype, NN); break;
         PFB_POW2_SIZES(X)
 #undef X
@@ -1962,6 +2222,8 @@ int pow2_prepare(pfb_conv_plan* p) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
         ft->num_cu = prop.multiProcessorCount;
     if (ft->num_cu <= 0) ft->num_cu = 256;
+    ft->col_x = p->nx >= 8192 ? 1 : 0;
+    if (const char* e = getenv("PFB_COL_X")) ft->col_x = (atoi(e) && p->nx >= 2048) ? 1 : 0;
     if (const char* e = getenv("PFB_CU_LIMIT")) { int v = atoi(e); if (v >= 16 && v < ft->num_cu) ft->num_cu = v; }   // experiments: leave CUs to a concurrent kernel
     return p->dtype == PFB_F32 ? prep_tables<float>(p, ft) : prep_tables<double>(p, ft);
 }
@@ -1971,6 +2233,7 @@ void pow2_release(pfb_conv_plan* p) {
     if (!ft) return;
     if (ft->ptw_col) (void)hipFree(ft->ptw_col);
     if (ft->ptwc_col) (void)hipFree(ft->ptwc_col);
+    if (ft->ptwc_col_x) (void)hipFree(ft->ptwc_col_x);
     if (ft->ptw_row) (void)hipFree(ft->ptw_row);
     if (ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv);
     if (ft->twM) (void)hipFree(ft->twM);
@@ -1986,7 +2249,8 @@ static int set_psfhat_t(pfb_conv_plan* p, const void* psfhat, hipStream_t st) {
     PFB_HIP_CHECK(hipMemsetAsync(p->psf_l, 0, sizeof(cplx<T>) * p->psf_elems_per_band * p->nband, st));
     dim3 grid((nv + 31) / 32, (p->P + 31) / 32, p->nband);
     hipLaunchKernelGGL((k_relayout_psf_pow2<T>), grid, dim3(256), 0, st, (const cplx<T>*)psfhat,
-                       (cplx<T>*)p->psf_l, p->P, nv, p->ny / 2, FastCfg<T>::NVB, p->psf_elems_per_band);
+                       (cplx<T>*)p->psf_l, p->P, nv, p->ny / 2, FastCfg<T>::NVB, p->psf_elems_per_band,
+                       ((const FastTables*)p->fast_tables)->col_x);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
@@ -2031,7 +2295,7 @@ static int set_psf_t(pfb_conv_plan* p, const void* psf, void* psfhat_out, hipStr
         const int nv = p->M + 1;
         dim3 grid((nv + 31) / 32, (P + 31) / 32, p->nband);
         hipLaunchKernelGGL((k_unrelayout_psf_pow2<T>), grid, dim3(256), 0, st, (const cplx<T>*)p->psf_l,
-                           (cplx<T>*)psfhat_out, P, nv, L, FastCfg<T>::NVB, p->psf_elems_per_band);
+                           (cplx<T>*)psfhat_out, P, nv, L, FastCfg<T>::NVB, p->psf_elems_per_band, ft->col_x);
     }
     if (rc == PFB_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
         set_error("pow2_set_psf: kernel launch failed");
@@ -2054,6 +2318,33 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
     using F = RegFft<T, H, E>;
     constexpr int GC = col_groups<H, E>();
     const int nblk = fast_nblocks(p->ny / 2, FastCfg<T>::NVB);
+    if constexpr (H >= 2048) {
+        if (ft->col_x) {
+            // two-level kernel: HS = H / 2 point sub-transforms, one resident workgroup set (2 waves per SIMD)
+            using CX = ColX<T, H, ECOLX>;
+            using FX = typename CX::F;
+            constexpr int GX = CX::GC;
+            const int nitems = nblk * nb;
+            static const bool rev = [] { const char* e = getenv("PFB_COL_REV"); return !e || atoi(e); }();
+            static const bool psf_nt_on = [] { const char* e = getenv("PFB_PSF_NT"); return !e || atoi(e); }();
+            const bool psf_nt = psf_nt_on && sizeof(cplx<T>) * p->psf_elems_per_band * (size_t)nb >= ((size_t)200 << 20);
+            const int wg_lds = (int)(((size_t)160 * 1024) / CX::LDS);
+            int wg_per_cu = (8 * 64) / (GX * FX::TPB) > 0 ? (8 * 64) / (GX * FX::TPB) : 1;
+            if (wg_per_cu > wg_lds) wg_per_cu = wg_lds > 0 ? wg_lds : 1;
+            int grid = ft->num_cu * wg_per_cu;
+            const int need = (nitems + GX - 1) / GX;
+            if (grid > need) grid = need;
+            const size_t ldsx = CX::LDS;
+#define PFB_COLX(NTV)                                                                                          \
+            hipLaunchKernelGGL((k_col_pow2x<T, H, ECOLX, NTV>), dim3(grid), dim3(GX * FX::TPB), ldsx, st,      \
+                               (cplx<T>*)p->T, (const cplx<T>*)p->psf_l, (const cplx<T>*)p->twP,               \
+                               (const cplx<T>*)ft->ptwc_col_x, nblk, nitems, p->T_elems_per_band,              \
+                               p->psf_elems_per_band, rev ? band0 + nb - 1 : band0, rev ? -1 : 1)
+            if (psf_nt) PFB_COLX(true); else PFB_COLX(false);
+#undef PFB_COLX
+            return;
+        }
+    }
     const size_t lds = sizeof(cplx<T>) * (size_t)GC * FastCfg<T>::NVB * F::LDS_ELEMS;
     // persistent kernel: needs its LDS (exchange buffers + twiddle table) to fit; measured faster
     // for H >= 2048 (fp32, packed arithmetic: 1.07 vs 1.32 ms at 4096^2 x 8, 0.276 vs 0.347 at 2048^2 x 8;
@@ -2125,7 +2416,14 @@ static int col_set_attr_t(int H) {
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2p<T, NN, ecol<T, NN>(), true, true, true>), \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_fwd_pow2<T, NN, ecol<T, NN>()>),                \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max)); break;
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));              \
+        if constexpr (NN >= 2048) {                                                                           \
+            PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2x<T, NN, ECOLX, false>),                \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));          \
+            PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_col_pow2x<T, NN, ECOLX, true>),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));          \
+        }                                                                                                     \
+        break;
         PFB_POW2_SIZES(X)
 #undef X
         default: set_error("pow2: unsupported nx"); return PFB_ERR_UNSUPPORTED;
@@ -2160,7 +2458,7 @@ static void launch_col_fwd(pfb_conv_plan* p, const FastTables* ft, const void* T
     const size_t lds = sizeof(cplx<T>) * (size_t)GC * NVB * F::LDS_ELEMS;
     hipLaunchKernelGGL((k_col_fwd_pow2<T, H, E>), dim3((nblk + GC - 1) / GC), dim3(GC * F::TPB), lds, st,
                        (const cplx<T>*)Tq, (cplx<T>*)p->psf_l + (size_t)band * p->psf_elems_per_band,
-                       (const cplx<T>*)p->twP, (const cplx<T>*)ft->ptw_col, nblk, nbe, p->T_elems_per_band);
+                       (const cplx<T>*)p->twP, (const cplx<T>*)ft->ptw_col, nblk, nbe, p->T_elems_per_band, ft->col_x);
 }
 template <typename T>
 static int col_fwd_launch_t(pfb_conv_plan* p, const FastTables* ft, const void* Tq, int band, hipStream_t st) {

@@ -19,8 +19,13 @@ crosses GPUs:
     Python at all: `native_comm()` builds an RCCL communicator inside libpfb_hip
     (include/pfb_hip.h: pfb_comm_*) and pfb_pcg_solve is handed the C function
     pfb_comm_allreduce, which enqueues the all-reduce on the solver's own stream.  The
-    torch hook stays as the fallback (gloo, CPU rehearsals, PFB_NATIVE_COMM=0, or any rank
-    failing to build the communicator -- the ranks agree on the choice collectively).
+    torch hook is the DEFAULT beyond world size 1 (the native exchange has not run on more than one GPU
+    yet: opt in with PFB_NATIVE_COMM=1) and the fallback (gloo, CPU rehearsals, any rank failing to
+    build the communicator -- the ranks agree on the choice collectively).
+
+Failure handling (include/pfb_hip.h, "Failure protocol"): neither exchange waits unboundedly.  A rank whose hook
+fails, whose communicator reports an asynchronous error, or whose stream makes no progress for
+PFB_COMM_TIMEOUT_S seconds aborts the exchange and raises _lib.PfbCommError; it must exit non-zero.
 """
 import ctypes as C
 import os
@@ -41,27 +46,79 @@ def shard_bands(nband, rank, world):
     return band0, nb
 
 
+class ExchangeFailed(RuntimeError):
+    """Raised inside AllReduceHook when the collective could not complete (peer gone, timeout)."""
+
+
+def comm_timeout_s():
+    """Seconds a rank waits for the exchange before it declares it failed (PFB_COMM_TIMEOUT_S, default 600): the
+    same knob bounds the C solver's waits for the device (include/pfb_hip.h, "Failure protocol")."""
+    try:
+        v = float(os.environ.get('PFB_COMM_TIMEOUT_S', '600'))
+    except ValueError:
+        v = 600.0
+    return v if v > 0 else 600.0
+
+
 class AllReduceHook:
     """Callable(buf_address, count) used by opt.pcg.pcg_fused: sums `count` fp64 scalars
     living inside `work` (the solver's device scratch) over the process group, in place.
-    Device agnostic (CPU tensors + gloo in the tests, GPU tensors + RCCL in production)."""
+    Device agnostic (CPU tensors + gloo in the tests, GPU tensors + RCCL in production).
+
+    It also speaks the failure protocol of pfb_allreduce_fn (include/pfb_hip.h): count == 0 is a PROBE (raises once
+    the exchange has failed), count < 0 an ABORT request.  A collective on host tensors (gloo) is waited for with a
+    timeout -- a peer that died or never arrives turns into ExchangeFailed within PFB_COMM_TIMEOUT_S instead of a
+    hang; on GPU tensors the collective is stream-ordered and the C solver's bounded wait does the timing.  After a
+    failure the hook refuses every further call: the reference's sums run over all bands in one process
+    (pfb/opt/pcg.py:90-107) and a partial sum must never be mistaken for one."""
 
     def __init__(self, work, group=None):
         self.work = work
         self.group = group
         self.calls = 0
         self.host_s = 0.0            # host time spent inside the hook (enqueue of the collective), for bench.py
+        self.failed = None           # text of the first failure
 
     def __call__(self, addr, count):
         import time
+        from datetime import timedelta
+        if count < 0:                # abort: nothing may use this exchange any more
+            self.failed = self.failed or 'aborted by the solver'
+            abort_exchange(self.group)
+            return
+        if self.failed:
+            raise ExchangeFailed(self.failed)
+        if count == 0:               # probe: a torch process group has no portable asynchronous error query
+            return
         t0 = time.perf_counter()
         off = addr - self.work.data_ptr()
         if off < 0 or off + 8 * count > self.work.numel() * self.work.element_size():
             raise ValueError("allreduce buffer outside the solver workspace")
         view = self.work.view(torch.uint8)[off:off + 8 * count].view(torch.float64)
-        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        try:
+            if view.is_cuda:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if w.wait(timeout=timedelta(seconds=comm_timeout_s())) is False:
+                    raise ExchangeFailed("all-reduce timed out")
+        except Exception as e:       # a closed connection, a timeout, an aborted group
+            self.failed = f"all-reduce over the band shards failed: {e!r}"
+            raise ExchangeFailed(self.failed) from e
         self.calls += 1
         self.host_s += time.perf_counter() - t0
+
+
+def abort_exchange(group=None):
+    """Tear down what this process holds of the exchange over `group` so that no peer stays blocked on it: the
+    library-owned RCCL communicator is aborted (ncclCommAbort makes the peers' queued collectives fail); torch's own
+    process group is left to its watchdog / to process exit -- a rank that gets here is expected to exit non-zero."""
+    for key, c in list(_native.items()):
+        if c is not None and key[0] is group:
+            try:
+                c.abort()
+            except Exception:
+                pass
 
 
 class NativeComm:
@@ -85,6 +142,15 @@ class NativeComm:
             raise TypeError("NativeComm.all_reduce_: contiguous fp64 GPU tensor expected")
         _lib.check(self._lib.pfb_comm_allreduce(self.handle, _dev.ptr(t), t.numel(), _dev.stream()))
         return t
+
+    def check(self):
+        """Raise PfbCommError once a collective on this communicator has failed or it was aborted."""
+        from . import _lib
+        _lib.check(self._lib.pfb_comm_check(self.handle))
+
+    def abort(self):
+        if self.handle:
+            self._lib.pfb_comm_abort(self.handle)
 
     def close(self):
         if self.handle:
@@ -118,8 +184,12 @@ def native_comm(group=None, device=None):
     if key in _native:
         return _native[key]
     comm = None
-    usable = (os.environ.get('PFB_NATIVE_COMM', '1') != '0' and dist.is_available() and dist.is_initialized()
-              and dist.get_backend(group) == 'nccl' and torch.cuda.is_available())
+    # The library-owned communicator has only ever run at world size 1 (no multi-GPU node was available to this build):
+    # beyond that it is OPT-IN (PFB_NATIVE_COMM=1) and the torch.distributed hook -- the path the world-2 / 4 / 8 gloo
+    # tests cover -- is the default.  PFB_NATIVE_COMM=0 switches it off at every size.
+    want = os.environ.get('PFB_NATIVE_COMM', '')
+    usable = (want != '0' and live and dist.get_backend(group) == 'nccl' and torch.cuda.is_available()
+              and (want == '1' or dist.get_world_size(group) == 1))
     if usable:
         from . import _lib
         lib = _lib.load()
@@ -127,9 +197,15 @@ def native_comm(group=None, device=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         ok, err = 1, ''
         idbuf = (C.c_ubyte * 128)()
+        # everything that can fail LOCALLY happens before the first agreement, so that the one collective step left
+        # (ncclCommInitRank inside pfb_comm_init) is only entered when every rank is known to arrive
         try:
             path = _loaded_rccl_path()
             _lib.check(lib.pfb_comm_bind(path.encode() if path else None))
+            if dev.type != 'cuda' or not (0 <= (dev.index or 0) < torch.cuda.device_count()):
+                raise RuntimeError(f"no such device {dev}")
+            with torch.cuda.device(dev):
+                torch.cuda.current_stream().synchronize()       # the device answers
             if rank == 0:
                 _lib.check(lib.pfb_comm_unique_id(idbuf))
         except Exception as e:      # this rank cannot: tell the others below
@@ -152,6 +228,7 @@ def native_comm(group=None, device=None):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
             if flag.item() >= 1.0:
                 comm = NativeComm(handle, lib)
+                _register_atexit()
             elif ok:
                 lib.pfb_comm_destroy(handle)
         if comm is None and err:
@@ -166,6 +243,19 @@ def close_native_comms():
         if c is not None:
             c.close()
     _native.clear()
+
+
+_atexit_done = False
+
+
+def _register_atexit():
+    """The communicators are destroyed when the interpreter exits, BEFORE torch tears its process group down (atexit
+    runs in reverse registration order and this is registered after torch.distributed was initialised)."""
+    global _atexit_done
+    if not _atexit_done:
+        import atexit
+        atexit.register(close_native_comms)
+        _atexit_done = True
 
 
 def global_max(value, device, group=None):

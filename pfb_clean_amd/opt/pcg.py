@@ -174,10 +174,11 @@ def pcg_fused(A, b, x0=None, mdiv=0.0, tol=1e-5, maxit=500, minit=100, backtrack
 
         def _hook(ctx, buf, count, stream):
             try:
-                allreduce(buf, count)
+                allreduce(buf or 0, count)      # count == 0: probe, count < 0: abort (include/pfb_hip.h)
                 return 0
             except Exception as e:   # never let an exception cross the C boundary
-                print(f"pfb_clean_amd: allreduce hook failed: {e!r}", file=sys.stderr)
+                if count > 0:
+                    print(f"pfb_clean_amd: allreduce hook failed: {e!r}", file=sys.stderr)
                 return 1
         cb = _lib.ALLREDUCE_FN(_hook)
     with plan.lock:            # a plan is single-owner (include/pfb_hip.h): one solve at a time per plan

@@ -75,6 +75,34 @@ def test_filter_tables_match_oracle_and_are_orthonormal():
         filter_bank('sym4')
 
 
+def test_wavelet_level_bookkeeping_matches_the_oracle_and_entry_points_refuse_the_host():
+    """pfb_clean_amd.wavelets.level_sizes (what callers of the stand-alone dwt2d / idwt2d pass as ix, iy, sx, sy, spx,
+    spy; psi.py:60-94) against the oracle's bookkeeping on even, odd and ragged shapes; and the stand-alone entry points
+    check their arguments and then insist on a device -- no host transform."""
+    import torch
+    from pfb_clean_amd.wavelets import level_sizes, dwt2d, idwt2d, filter_bank
+    from oracle import wavelets as owv
+    for nx, ny in ((128, 256), (512, 128), (129, 255), (250, 78), (33, 47)):
+        for K in (1, 2, 4, 5, 9):
+            for nlevel in (1, 2, 3):
+                sx, sy, spx, spy, ix, iy, ntx, nty = level_sizes(nx, ny, 2 * K, nlevel)
+                bk = owv.Bookkeeping(nx, ny, 2 * K, nlevel)
+                assert (list(sx), list(sy), list(spx), list(spy)) == (bk.sx, bk.sy, bk.spx, bk.spy)
+                assert ix == bk.ix and iy == bk.iy and (ntx, nty) == (bk.Ntotx, bk.Ntoty)
+    dl, dh, rl, rh = filter_bank('db2')
+    sx, sy, spx, spy, ix, iy, ntx, nty = level_sizes(64, 48, 4, 2)
+    img, co = np.zeros((64, 48)), np.zeros((nty, ntx))
+    with pytest.raises(ValueError):                                 # wrong packed shape: refused before any device work
+        dwt2d(img, np.zeros((nty, ntx + 1)), None, None, ix, iy, sx, sy, dl, dh, 2)
+    with pytest.raises(ValueError):
+        idwt2d(co, img, None, None, None, ix, iy, sx, sy, spx, tuple(v + 2 for v in spy), rl, rh, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            dwt2d(img, co, None, None, ix, iy, sx, sy, dl, dh, 2)
+        with pytest.raises(RuntimeError):
+            idwt2d(co, img, None, None, None, ix, iy, sx, sy, spx, spy, rl, rh, 2)
+
+
 def test_shard_bands():
     from pfb_clean_amd.dist import shard_bands
     for nband in (1, 3, 8, 16, 17):
@@ -111,19 +139,36 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _synthetic_cube(nband, n=16, seed=31):
+    """A small positive-definite cube problem with `nband` bands (the golden fixture has three): a BASELINE-like band
+    count (8 = C3, 16 = C5) for the world-4 / world-8 shard rehearsals."""
+    rng = np.random.default_rng(seed)
+    P = Q = 2 * n
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    psfhat = np.stack([np.exp(-(u ** 2 + v ** 2) / (2 * (0.15 + 0.01 * k) ** 2)) for k in range(nband)]) / nband + 0.02
+    b = rng.standard_normal((nband, n, n))
+    beam = 0.5 + rng.random((nband, n, n))
+    return psfhat.astype(np.complex128), b, beam, 0.3, Q
+
+
+def _worker(rank, world, port, q, nband_syn=0):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from pfb_clean_amd.dist import shard_bands, AllReduceHook, global_max
         from oracle import fftconv as ofc, solvers as osv
-        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pcg.npz'))
-        psfhat, b, beam = g['psfhat'], g['b'], g['beam']
-        sigmainv, Q = float(g['sigmainv']), int(g['Q'])
+        if nband_syn:
+            psfhat, b, beam, sigmainv, Q = _synthetic_cube(nband_syn)
+        else:
+            g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pcg.npz'))
+            psfhat, b, beam = g['psfhat'], g['b'], g['beam']
+            sigmainv, Q = float(g['sigmainv']), int(g['Q'])
         nband = b.shape[0]
         band0, nb = shard_bands(nband, rank, world)
         sl = slice(band0, band0 + nb)
@@ -175,7 +220,6 @@ def _worker(rank, world, port, q):
             rho = rho_n
             k += 1
             eps = np.sqrt(num / (1e-12 + den))
-        ref = g['cube_k10_x'] if False else None
         # reference: single-process cube PCG with the same preconditioner
         xpadf, xhatf, xoutf = ofc.make_scratch(psfhat, Q, b.shape, np.float64)
 
@@ -203,6 +247,91 @@ def test_band_sharded_cube_pcg_gloo_world2():
     for rank, err, calls in res:
         assert err < 1e-10, (rank, err)
         assert calls >= 1 + 1 + 3 * 10       # self-test + init + >= 3 reductions per iteration
+
+
+@pytest.mark.parametrize('world,nband', [(4, 8), (8, 16)])
+def test_band_sharded_cube_pcg_gloo_world4_and_8(world, nband):
+    """The BASELINE shardings -- 8 bands over 4 ranks (C3 at 4 GPUs), 16 bands over 8 ranks (C5: two bands per GPU)
+    -- through shard_bands and the solver's all-reduce hook, against the single-process cube solve."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, nband)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [r[0] for r in res] == list(range(world))
+    for rank, err, calls in res:
+        assert err < 1e-10, (rank, err)
+
+
+def _failing_worker(rank, world, port, q, mode):
+    """Rank 1 drops out of the exchange after two good all-reduces (mode 'exit': it raises inside its hook and the
+    process ends non-zero; mode 'stall': it stays alive but never arrives).  Rank 0 must get an error from its hook
+    within the bound, refuse every further use of the exchange, and end non-zero itself."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from datetime import timedelta
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['PFB_COMM_TIMEOUT_S'] = '4'
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=timedelta(seconds=60))
+    from pfb_clean_amd.dist import AllReduceHook, ExchangeFailed
+    work = torch.zeros(1024, dtype=torch.uint8)
+    S = work[256:256 + 64].view(torch.float64)
+    hook = AllReduceHook(work, None)
+    for k in range(2):
+        S[0] = rank + 1.0
+        hook(S.data_ptr(), 1)
+        assert S[0].item() == 3.0
+    if rank == 1:
+        if mode == 'stall':
+            time.sleep(12)
+        os._exit(7)                       # a rank whose hook failed ends non-zero, without a clean group shutdown
+    t0 = time.perf_counter()
+    try:
+        hook(S.data_ptr(), 1)
+        q.put((rank, 'no error', 0.0))
+        q.close()
+        q.join_thread()
+        os._exit(0)
+    except ExchangeFailed as e:
+        took = time.perf_counter() - t0
+        again = 0
+        for count in (1, 0):              # the exchange and its probe both refuse from now on
+            try:
+                hook(S.data_ptr(), count)
+            except ExchangeFailed:
+                again += 1
+        hook(0, -1)                       # abort request: accepted, idempotent
+        q.put((rank, f'failed:{again}:{str(e)[:60]}', took))
+        q.close()
+        q.join_thread()                   # the feeder thread has written the message before the hard exit
+        os._exit(3)
+
+
+@pytest.mark.parametrize('mode', ['exit', 'stall'])
+def test_exchange_failure_on_one_rank_is_bounded_on_the_other(mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(60)
+    assert procs[1].exitcode == 7
+    assert procs[0].exitcode == 3, procs[0].exitcode
+    rank, what, took = q.get(timeout=5)
+    assert rank == 0 and what.startswith('failed:2:'), what
+    assert took < 10.0, took              # PFB_COMM_TIMEOUT_S = 4 (+ slack), not gloo's 60 s / 30 min
 
 
 def _pd_worker(rank, world, port, q):

@@ -714,6 +714,51 @@ def test_fp32_predictive_backtracking_matches_reference_loop(amd, n, nb):
         assert r_gpu < 1.5 * r_ref + 1e-6 * np.linalg.norm(b64), (res.backtracks, nbt_ref, r_gpu, r_ref)
 
 
+@pmp('rdt', [np.float64, np.float32])
+def test_config1_fifty_iterations_through_the_reference_entry_point(amd, rdt):
+    """BASELINE config #1 as it is worded: 1024 x 1024, one band, dirty + PSF, FIFTY PCG iterations (tol = 0,
+    minit = maxit = 50 -> 51 matvecs) through the drop-in `pcg(A, b, x0, M, ...)` with A = _hessian_psf_slice bound by
+    functools.partial, the way the reference's workers bind it (pcg.py:262-267), against the fp64 oracle on the same
+    inputs: fp64 iterates to 1e-9 (every backtracking decision must coincide), fp32 to the stated 1e-3 when the
+    backtracking histories coincide and otherwise through the residual of the normal equations (see
+    test_fp32_predictive_backtracking_matches_reference_loop for why fp32 is pinned only up to line-search ties)."""
+    n, nit = 1024, 50
+    rng = np.random.default_rng(420)
+    P = Q = 2 * n
+    u = np.fft.fftfreq(P)[:, None]
+    v = np.fft.rfftfreq(Q)[None, :]
+    W = rng.poisson(4.0 * np.exp(-(u ** 2 + v ** 2) / (2 * 0.12 ** 2)), size=(P, Q // 2 + 1)).astype(np.float64)
+    ph128 = (W / np.fft.irfft2(W, s=(P, Q))[0, 0]).astype(np.complex128)
+    model = np.zeros((n, n))
+    for _ in range(25):
+        i, j = rng.integers(n // 8, 7 * n // 8, size=2)
+        model[i, j] += 1 + rng.random()
+    xpad, xhat, xout = ofc.make_scratch(ph128, Q, model.shape, np.float64)
+    b64 = ofc.psf_convolve_slice(xpad, xhat, xout, ph128, Q, model).copy() + 1e-3 * rng.standard_normal(model.shape)
+    sigmainv = 1e-3 * np.abs(b64).max()
+    Ao = lambda w: ofc._hessian_psf_slice(xpad, xhat, xout, ph128, None, Q, w, sigmainv=sigmainv)
+    tr = osv.PCGTrace()
+    xo = osv.pcg(Ao, b64, None, M=lambda w: w / sigmainv, tol=0.0, maxit=nit, minit=nit, trace=tr)
+    assert tr.k_exit == nit
+    cdt = np.complex128 if rdt == np.float64 else np.complex64
+    ph = torch.from_numpy(ph128.astype(cdt)).cuda()
+    b = torch.from_numpy(b64.astype(rdt)).cuda()
+    A = partial(amd.hessian._hessian_psf_slice, None, None, None, ph, None, Q, sigmainv=sigmainv)
+    x = amd.pcg.pcg(A, b, None, M=lambda w: w / sigmainv, tol=0.0, maxit=nit, minit=nit, verbosity=0)
+    xh = x.cpu().numpy().astype(np.float64)
+    if rdt == np.float64:
+        assert relerr(xh, xo) < TOL_PCG[np.float64]
+    else:
+        r_gpu, r_ref = np.linalg.norm(Ao(xh) - b64), np.linalg.norm(Ao(xo) - b64)
+        assert r_gpu < 1.5 * r_ref + 1e-6 * np.linalg.norm(b64), (r_gpu, r_ref)
+        if relerr(xh, xo) >= 5 * TOL_PCG[np.float32]:
+            # a different -- equally valid -- backtracking history: allowed only if the solve says so itself
+            res = amd.pcg.pcg_fused(amd.hessian.HessianPsf(ph, n, n, Q, sigmainv=sigmainv), b[None], None, mdiv=sigmainv,
+                                    tol=0.0, maxit=nit, minit=nit)[2]
+            assert res.backtracks != int(np.sum(tr.nbacktrack)), (relerr(xh, xo), res.backtracks)
+    amd.psf.clear_plan_cache()
+
+
 def test_long_line_coverage_path_runs_the_fused_pcg(amd):
     """A grid neither the LDS kernels nor the fast path can hold (nx = 9000 > 8192, nx_psf = 18000): the plan takes the
     long-line coverage path (every FFT as global-memory passes) and the fused PCG on it -- fused dots out of its

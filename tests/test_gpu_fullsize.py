@@ -287,6 +287,108 @@ def test_config4_pointwise_vs_oracle_at_full_size():
         torch.cuda.empty_cache()
 
 
+def test_config5_psi_and_primal_dual_half_at_full_size():
+    """The wavelet / primal-dual half of BASELINE config #5 on its per-GPU shard: 2 bands x 8192 x 8192, fp64, bases
+    self + db1..db4, 3 levels (Ntot = Nxmax = Nymax = 8212; reference operators/psi.py:60-94, 187-256,
+    opt/primal_dual.py:91-180, tests/test_psi_operator.py:14-48):
+      * hdot(dot(x)) = nbasis x to 1e-12, adjointness on the written cells, the dual-update identity -- on both bands;
+      * POINTWISE against the CPU oracle: psi.dot / psi.hdot of one band (the numpy wavelets need tens of seconds per
+        band at this size), and two iterations of primal_dual_optimised with the live operators (psi, psi^H, l21 dual
+        update, PSF-convolution gradient on the 16384^2 PSF grid, positivity).  The dual update couples the bands
+        through |sum_b v|; with two IDENTICAL bands it equals the one-band update with lambda / 2, so the oracle runs
+        ONE band with lambda / 2 and both GPU bands must reproduce it."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import fftconv as ofc, solvers as osv, wavelets as owv      # checker only
+    from pfb_clean_amd.operators.psi import Psi
+    from pfb_clean_amd.operators.psf import PsfConvPlan
+    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised, PsfGradient
+    from pfb_clean_amd.prox.prox_21m import dual_update_numba
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(15)
+    nb, n, nlev = 2, 8192, 3
+    bases = ['self', 'db1', 'db2', 'db3', 'db4']
+    nbasis = len(bases)
+    dt = torch.float64
+    psi = Psi(nb, n, n, bases, nlev, 1, dtype=dt)
+    assert (psi.Nxmax, psi.Nymax) == (8212, 8212)
+    # ---- properties on the two-band cube
+    x = torch.randn((nb, n, n), generator=g, device=dev, dtype=dt)
+    a = torch.zeros((nb, nbasis, psi.Nymax, psi.Nxmax), device=dev, dtype=dt)
+    psi.dot(x, a)
+    back = torch.full_like(x, 7.0)                     # hdot must overwrite, not accumulate into, its output
+    psi.hdot(a, back)
+    assert (back - nbasis * x).abs().max().item() < 1e-12 * nbasis * x.abs().max().item()
+    del back
+    c = torch.randn(a.shape, generator=g, device=dev, dtype=dt) * (a != 0)      # the cells psi writes
+    ht = torch.empty_like(x)
+    psi.hdot(c, ht)
+    lhs = torch.sum(a * c).item()
+    rhs = torch.sum(x * ht).item()
+    assert abs(lhs - rhs) < 1e-12 * (torch.linalg.vector_norm(a) * torch.linalg.vector_norm(c)).item()
+    lam, sigma = 0.3, 1.7
+    w = torch.rand(a.shape[1:], generator=g, device=dev, dtype=dt)
+    vp = torch.randn(a.shape, generator=g, device=dev, dtype=dt)
+    vt = vp + sigma * a
+    l2 = torch.abs(vt.sum(dim=0) / sigma)
+    ratio = torch.clamp(l2 - lam * w / sigma, min=0.0) / torch.where(l2 != 0, l2, torch.ones_like(l2))
+    want = vt - vt * ratio[None]
+    del vt, l2, ratio
+    v = a.clone()
+    dual_update_numba(vp, v, lam, sigma=sigma, weight=w)
+    assert (v - want).abs().max().item() < 1e-11 * want.abs().max().item()
+    del v, vp, want, w
+    torch.cuda.empty_cache()
+    # ---- pointwise: one band of psi / psi^H against the oracle
+    po = owv.Psi(1, n, n, bases, nlev)
+    assert (po.Nxmax, po.Nymax) == (psi.Nxmax, psi.Nymax)
+    x0 = x[:1].cpu().numpy()
+    a_ref = np.zeros((1, nbasis, po.Nymax, po.Nxmax))
+    po.dot(x0, a_ref)
+    assert np.abs(a[:1].cpu().numpy() - a_ref).max() < 1e-12 * np.abs(a_ref).max()
+    c0 = c[:1].cpu().numpy()
+    y_ref = np.zeros((1, n, n))
+    po.hdot(c0, y_ref)
+    assert np.abs(ht[:1].cpu().numpy() - y_ref).max() < 1e-12 * np.abs(y_ref).max()
+    del a, c, ht, x, a_ref, y_ref
+    torch.cuda.empty_cache()
+    # ---- two primal-dual iterations, two identical bands on the GPU against one band of the oracle with lambda / 2
+    rng = np.random.default_rng(45)
+    Q = 2 * n
+    u = np.fft.fftfreq(Q)[:, None]
+    vf = np.fft.rfftfreq(Q)[None, :]
+    psfhat = (np.exp(-(u ** 2 + vf ** 2) / (2 * 0.05 ** 2)) + 1e-3)[None].astype(np.complex128)
+    model = np.zeros((1, n, n))
+    idx = rng.integers(0, n, size=(400, 2))
+    model[0, idx[:, 0], idx[:, 1]] = rng.random(400) + 0.5
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, model.shape, np.float64)
+    dirty = ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, model).copy()
+    dirty += 1e-3 * rng.standard_normal(dirty.shape)
+    xs = 0.1 * rng.random((1, n, n))
+    vs = 0.05 * c0
+    lam, L = 2e-3, 1.0
+    wn = np.ones((nbasis, po.Nymax, po.Nxmax))
+    xo, vo = xs.copy(), vs.copy()
+    osv.primal_dual_optimised(xo, vo, lam / 2, po.hdot, po.dot, L, None, wn, None,
+                              lambda t: ofc.psf_convolve_cube(xpad, xhat, xout, psfhat, Q, t) - dirty,
+                              nu=nbasis, tol=0.0, maxit=2, positivity=1, verbosity=0)
+    ph2 = torch.from_numpy(np.repeat(psfhat, nb, axis=0)).cuda()
+    plan = PsfConvPlan(ph2, n, n, Q)
+    assert plan.fast_path
+    del ph2
+    grad = PsfGradient(plan, torch.from_numpy(np.repeat(dirty, nb, axis=0)).cuda())
+    xg = torch.from_numpy(np.repeat(xs, nb, axis=0)).cuda()
+    vg = torch.from_numpy(np.repeat(vs, nb, axis=0)).cuda()
+    xg, vg = primal_dual_optimised(xg, vg, lam, psi.hdot, psi.dot, L, None, torch.from_numpy(wn).cuda(), None,
+                                   grad, nu=nbasis, tol=0.0, maxit=2, positivity=1, verbosity=0)
+    for b in range(nb):
+        assert np.abs(xg[b].cpu().numpy() - xo[0]).max() < 1e-10 * np.abs(xo).max(), b
+        assert np.abs(vg[b].cpu().numpy() - vo[0]).max() < 1e-10 * np.abs(vo).max(), b
+    plan.close()
+    del psi, xg, vg, grad
+    torch.cuda.empty_cache()
+
+
 def test_fp32_pcg_iterates_track_fp64_at_full_size():
     """The stated fp32 tolerance for PCG iterates (1e-3 relative) at the headline image
     size: 20 fused PCG iterations on a 2-band 4096^2 cube in fp32 against the same solve in fp64 (the fp64

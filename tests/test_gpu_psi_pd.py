@@ -114,6 +114,55 @@ def test_dwt_idwt_roundtrip_and_layout(amd, wavelet, shape, nlevel):
     assert maxerr(rec, data) < 1e-12
 
 
+@pmp("wavelet", ["db1", "db4", "db5"])
+@pmp("shape", [(128, 256), (512, 128)])
+@pmp("nlevel", [1, 2, 3])
+def test_standalone_dwt2d_idwt2d_with_the_reference_argument_lists(amd, wavelet, shape, nlevel):
+    """pfb.wavelets.dwt2d / idwt2d as the reference's own test calls them (tests/test_wavelets.py:11-109: same
+    wavelets, shapes and level counts; wavelets.py:175-213, 261-315 for the argument lists): scratch buffers and
+    bookkeeping handed in positionally, outputs written in place, reconstruction to 1e-12 and the packed layout equal
+    to the oracle's (which is pinned to the reference's by tests/golden/psi.npz)."""
+    from pfb_clean_amd.wavelets import dwt2d, idwt2d, level_sizes, filter_bank, coeff_size, signal_size
+    rng = np.random.default_rng(12)
+    nx, ny = shape
+    dec_lo, dec_hi, rec_lo, rec_hi = filter_bank(wavelet)
+    F = dec_lo.size
+    sx, sy, spx, spy, ix, iy, ntx, nty = level_sizes(nx, ny, F, nlevel)
+    bk = owv.Bookkeeping(nx, ny, F, nlevel)
+    assert (ntx, nty) == (bk.Ntotx, bk.Ntoty) and list(sx) == bk.sx and list(spy) == bk.spy and ix == bk.ix and iy == bk.iy
+    assert sx[0] == coeff_size(nx, F) and spx[0] == signal_size(sx[0], F)
+    data = rng.random((nx, ny))
+    alpha2 = np.full((nty, ntx), 3.5)                     # cells outside the level blocks must keep this value
+    cbuff, cbuffT = np.zeros((ntx, nty)), np.zeros((nty, ntx))
+    keep = data.copy()
+    out = dwt2d(data, alpha2, cbuff, cbuffT, ix, iy, sx, sy, dec_lo, dec_hi, nlevel)
+    assert out is alpha2 and np.array_equal(data, keep)
+    want = np.full((nty, ntx), 3.5)
+    owv.dwt2d(data, want, bk, dec_lo, dec_hi)
+    assert maxerr(alpha2, want) < 1e-13
+    xrec2 = np.full((nx, ny), -1.0)
+    coeffs_scratch = np.zeros((nty, ntx))
+    before = alpha2.copy()
+    idwt2d(alpha2, xrec2, coeffs_scratch, cbuff, cbuffT, ix, iy, sx, sy, spx, spy, rec_lo, rec_hi, nlevel)
+    np.testing.assert_array_almost_equal(data, xrec2, decimal=12)
+    assert np.array_equal(alpha2, before)                 # the input coefficients are not modified
+    # device tensors, fp32
+    d32 = torch.from_numpy(data.astype(np.float32)).cuda()
+    a32 = torch.zeros((nty, ntx), dtype=torch.float32, device='cuda')
+    assert dwt2d(d32, a32, None, None, ix, iy, sx, sy, dec_lo, dec_hi, nlevel) is a32
+    w0 = np.zeros((nty, ntx))
+    owv.dwt2d(data, w0, bk, dec_lo, dec_hi)
+    assert maxerr(a32.cpu().numpy(), w0) < 5e-6 * np.abs(w0).max()
+    r32 = torch.empty_like(d32)
+    idwt2d(a32, r32, None, None, None, ix, iy, sx, sy, spx, spy, rec_lo, rec_hi, nlevel)
+    assert maxerr(r32.cpu().numpy(), data) < 2e-5
+    # bookkeeping that does not belong to this transform is refused, not followed
+    with pytest.raises(ValueError):
+        dwt2d(data, np.zeros((nty + 1, ntx)), cbuff, cbuffT, ix, iy, sx, sy, dec_lo, dec_hi, nlevel)
+    with pytest.raises(ValueError):
+        dwt2d(data, alpha2, cbuff, cbuffT, ix, iy, tuple(v + 1 for v in sx), sy, dec_lo, dec_hi, nlevel)
+
+
 def test_psi_device_tensors_adjoint_and_errors(amd):
     rng = np.random.default_rng(9)
     nband, nx, ny = 2, 96, 80

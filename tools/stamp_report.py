@@ -36,6 +36,14 @@ NAMES = {
                             'build (odd)', 'IFFT (odd)', 'wait x, r; epilogue + stores issued']),
 }
 
+if n >= 8192 or os.environ.get('PFB_COL_X', '0') not in ('', '0'):
+    # two-level column kernel (k_col_pow2x): four rounds (classes 0, 2, 1, 3) of FFT | multiply + IFFT | accumulate + next input
+    NAMES[1] = ('k_col_pow2x', ['r0: a_lo + a_hi, FFT', 'r0: wait psf, multiply, IFFT (psf class 2 requested)',
+                                'r0 -> r2: keep c0, form (a_lo - a_hi) w^2n', 'r2: FFT', 'r2: multiply, IFFT (class 1 requested)',
+                                'r2 -> r1: accumulate, park hi, form both odd-class inputs', 'r1: FFT (next a_hi requested)',
+                                'r1: multiply, IFFT (class 3 requested)', 'r1 -> r3: accumulate (park read-modify-write)',
+                                'r3: FFT (next a_lo requested)', 'r3: multiply, IFFT (next class 0 requested)',
+                                'combine + stores issued'])
 lib = _lib.load()
 raw = C.CDLL(_lib.LIB_PATH)
 raw.pfb_debug_set_stamps.argtypes = [C.c_void_p]
