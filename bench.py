@@ -215,12 +215,75 @@ def main():
             torch.cuda.synchronize()
     ctx = dict(args=args, world=world, rank=rank, device=device, use_pg=use_pg)
     out = bench_pd(ctx) if args.workload == 'pd' else bench_pcg(ctx)
+    headline = args.workload == 'pcg' and args.size is None and args.bands is None and args.dtype == 'f32'
+    if args.configs == 'all' or (args.configs == 'auto' and headline and world == 1 and not args.force_dist):
+        out["configs"] = extra_configs(ctx)
     if rank == 0:
         print(json.dumps(out))
     if use_pg:
         from pfb_clean_amd.dist import close_native_comms
         close_native_comms()
         dist.destroy_process_group()
+
+
+def extra_configs(ctx):
+    """The other BASELINE configs on this GPU, in the same run as the headline (so that the driver's record carries
+    them): C1 (1024^2 x 1), C2 (4096^2 x 1 = the per-GPU work of the 8-GPU run; also once with the band-shard
+    exchange live at world size 1, in a child process), C4 (the primal-dual iteration) and the C5 per-GPU shard
+    (8192^2 x 2 bands, fp64).  Same code paths and JSON shape as `--size/--bands/--dtype/--workload`; no CPU leg.
+    A config that fails reports its error instead of taking the headline down with it."""
+    import copy
+    import torch
+    args = ctx['args']
+
+    def brief(o):
+        r = o.get("roofline") or {}
+        keep = ("achieved", "frac", "unit", "ms_per_launch", "ms_per_iteration", "stage_ms", "alg_bytes_per_launch",
+                "alg_bytes_per_iteration", "traffic", "traffic_source", "traffic_commit", "traffic_stale",
+                "hbm_rate_from_traffic_GBs")
+        b = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+             "repeats": o["repeats"], "value_min": o["value_min"], "value_max": o["value_max"], "dtype": o["dtype"],
+             "workload": o["config"]["workload"], "roofline": {k: r[k] for k in keep if k in r}}
+        if "allreduce_hook" in o:
+            b["allreduce_hook"] = o["allreduce_hook"]
+        return b
+
+    specs = [
+        ("C1_1024x1_f32", "pcg", dict(size=1024, bands=1, dtype='f32', steps=50, warmup=5, repeats=3)),
+        ("C2_4096x1_f32", "pcg", dict(size=4096, bands=1, dtype='f32', steps=50, warmup=5, repeats=3)),
+        ("C4_pd_2048x4_f32", "pd", dict(size=2048, bands=4, dtype='f32', steps=20, warmup=3, repeats=3)),
+        ("C5_shard_8192x2_f64", "pcg", dict(size=8192, bands=2, dtype='f64', steps=5, warmup=2, repeats=3)),
+    ]
+    res = {}
+    for name, workload, kw in specs:
+        a = copy.copy(args)
+        a.no_cpu, a.configs, a.workload = True, 'none', workload
+        for k, v in kw.items():
+            setattr(a, k, v)
+        try:
+            o = (bench_pd if workload == 'pd' else bench_pcg)(dict(ctx, args=a))
+            res[name] = brief(o)
+        except Exception as e:          # noqa: BLE001 -- reported, never fatal for the headline
+            res[name] = {"error": repr(e)[:300]}
+        from pfb_clean_amd.operators.psf import clear_plan_cache
+        clear_plan_cache()
+        torch.cuda.empty_cache()
+    # C2 with the exchange of the sharded solve in the loop (RCCL communicator of ONE rank: what a GPU of the 8-GPU run
+    # executes per iteration, minus the wire): its own process, bounded -- a process group is never brought up in the
+    # process that owns the headline measurement
+    cmd = [sys.executable, os.path.abspath(__file__), '--bands', '1', '--steps', '50', '--warmup', '5', '--repeats', '3',
+           '--no-cpu', '--force-dist', '--configs', 'none']
+    try:
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), PFB_COMM_TIMEOUT_S='60')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        if p.returncode != 0 or not line:
+            raise RuntimeError(f"rc={p.returncode}: {p.stderr[-200:]}")
+        res["C2_4096x1_f32_exchange_world1"] = brief(json.loads(line[-1]))
+    except Exception as e:              # noqa: BLE001
+        res["C2_4096x1_f32_exchange_world1"] = {"error": repr(e)[:300]}
+    return res
 
 
 def _timed_regions(run, barrier, repeats, world, device):

@@ -286,6 +286,15 @@ int pfb_dual_bandsum(int dtype, const void* vp, const void* v, double sigma, int
                      size_t nper, void* sum_out, void* stream);
 int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in,
                    double lam, double sigma, int nband, size_t nper, void* vp_out, void* stream);
+/* The same two steps on a CHUNK of the coefficient plane, so that the exchange of one chunk (reduce-scatter +
+ * all-gather over xGMI) overlaps the band sums / threshold of its neighbours: every pointer is pre-offset to the
+ * chunk's first coefficient, `count` coefficients are processed, bands of vp / v / vp_out are `band_stride`
+ * elements apart (the full plane's nper), weight / sum are the chunk's slices. */
+int pfb_dual_bandsum_chunk(int dtype, const void* vp, const void* v, double sigma, int nband, size_t count,
+                           size_t band_stride, void* sum_out, void* stream);
+int pfb_dual_apply_chunk(int dtype, const void* vp, void* v, const void* weight, const void* sum_in,
+                         double lam, double sigma, int nband, size_t count, size_t band_stride,
+                         void* vp_out, void* stream);
 
 /* pfb/prox/prox_21m.py:31-61 prox_21m_numba */
 int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight,

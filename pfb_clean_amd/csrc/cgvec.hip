@@ -10,23 +10,13 @@
 // memory (alpha, beta are read by the kernels from there), the p.Ap product comes
 // fused out of the convolution epilogue (fftconv*.hip).
 #include "conv_plan.hpp"
+#include "pcg_state.hpp"
 #include <chrono>
 #include <unistd.h>
 #include <cstring>
 #include <cstdlib>
 
 namespace pfb {
-
-// scalar slots in the device state array
-enum { S_PAP = 0, S_RAP = 1, S_APAP = 2,          // <p,Ap>, <r,Ap>, <Ap,Ap>   (conv epilogue)
-       S_ANY = 3,                                 // count(p != 0) of the direction in use
-       S_RHON = 4, S_NUM = 5, S_DEN = 6,          // <r',y'>, |x'-x|^2, |x'|^2 (update kernel)
-       S_RHO = 7, S_ALPHA = 8, S_BETA = 9, S_NBT = 10,
-       S_DEAD = 11,                               // p became all-zero: later work is a no-op
-       S_K = 12, S_EPS = 13, S_EPSP = 14, S_NBTSUM = 15,
-       S_STOP = 16,                               // the stopping rule fired on the device: later work is a no-op
-       S_TOL = 17, S_MINIT = 18, S_MAXIT = 19,    // the rule's parameters (set once per solve)
-       S_NSCALAR = 20 };
 
 constexpr int RED_BLOCK = 256;
 constexpr int RED_MAX_GRID = 1024;
@@ -359,44 +349,6 @@ __global__ void k_scale_alpha(double* S) { S[S_ALPHA] *= 0.75; }
 __global__ void k_set_beta(double* S) { S[S_BETA] = S[S_RHON] / S[S_RHO]; }
 __global__ void k_accept_rho(double* S) { S[S_RHO] = S[S_RHON]; }
 
-// ---- device-side loop bookkeeping of the sync-free driver
-__device__ __forceinline__ void iter_begin_dev(double* S, double mdiv, int predict) {
-    if (S[S_DEAD] != 0.0 || S[S_STOP] != 0.0) return;
-    if (S[S_ANY] == 0.0) {                 // the direction built last iteration is all zero:
-        S[S_DEAD] = 1.0;                   // the reference broke BEFORE k += 1 (pcg.py:106-108)
-        S[S_K] -= 1.0;
-        S[S_EPS] = S[S_EPSP];
-        return;
-    }
-    const double rho = S[S_RHO];
-    double alpha = rho / S[S_PAP];
-    int nbt = 0;
-    if (predict == 1 || predict == 2) {
-        const double d = mdiv > 0.0 ? mdiv : 1.0;
-        const double s1 = S[S_RAP] / d, s2 = S[S_APAP] / d;
-        while (rho + (2.0 * alpha * s1 + alpha * alpha * s2) > rho && nbt < 200) { alpha *= 0.75; ++nbt; }
-    }
-    S[S_ALPHA] = alpha;
-    S[S_NBT] = (double)nbt;
-    if (predict >= 2) {                    // fused update+direction: beta from rho(alpha)
-        const double d = mdiv > 0.0 ? mdiv : 1.0;
-        S[S_BETA] = (rho + (2.0 * alpha * S[S_RAP] + alpha * alpha * S[S_APAP]) / d) / rho;
-    }
-}
-__device__ __forceinline__ void iter_end_dev(double* S, int fused) {
-    if (S[S_DEAD] != 0.0 || S[S_STOP] != 0.0) return;
-    if (!fused) S[S_BETA] = S[S_RHON] / S[S_RHO];
-    S[S_RHO] = S[S_RHON];
-    const double k = S[S_K] + 1.0;
-    const double eps = sqrt(S[S_NUM] / (1e-12 + S[S_DEN]));
-    S[S_K] = k;
-    S[S_EPSP] = S[S_EPS];
-    S[S_EPS] = eps;
-    S[S_NBTSUM] += S[S_NBT];
-    // the reference's loop condition (pcg.py:86), evaluated where the numbers are: an iteration the host
-    // enqueued speculatively behind this one finds S_STOP set and changes nothing
-    if (!((eps > S[S_TOL] || k < S[S_MINIT]) && k < S[S_MAXIT])) S[S_STOP] = 1.0;
-}
 // the fused update's four sums AND the end-of-iteration bookkeeping in one launch (no all-reduce between)
 __global__ void __launch_bounds__(256)
 k_final_sum_waves_end(const double* __restrict__ ws, int G, double* __restrict__ S) {
@@ -424,30 +376,7 @@ __global__ void __launch_bounds__(256)
 k_iter_sums(const double* __restrict__ cp, int ncp, const double* __restrict__ ws, int G, int have_upd,
             double* __restrict__ S, double mdiv, int predict, int logic) {
     __shared__ double vals[8];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // seven independent sums, each by ONE wave in a fixed lane-strided order (deterministic):
-    // wave w takes conv quantity w (w < 3) and update quantity w
-    if (w < 3) {
-        double acc = 0.0;
-        for (int k = lane; k < ncp; k += 64) acc += cp[(size_t)w * ncp + k];
-        acc = wave_sum(acc);
-        if (lane == 0) vals[w] = acc;
-    }
-    if (have_upd) {
-        double acc = 0.0;
-        for (int g = lane; g < G; g += 64) acc += ws[(size_t)w * G + g];
-        acc = wave_sum(acc);
-        if (lane == 0) vals[3 + w] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        S[S_PAP] = vals[0]; S[S_RAP] = vals[1]; S[S_APAP] = vals[2];
-        if (have_upd) { S[S_RHON] = vals[3]; S[S_NUM] = vals[4]; S[S_DEN] = vals[5]; S[S_ANY] = vals[6]; }
-        if (logic) {
-            if (have_upd) iter_end_dev(S, 1);
-            iter_begin_dev(S, mdiv, predict);
-        }
-    }
+    pcg_iter_sums<false>(cp, ncp, ws, G, have_upd, S, mdiv, predict, logic, vals);
 }
 __global__ void k_final_check(double* S) {
     if (S[S_DEAD] == 0.0 && S[S_ANY] == 0.0) { S[S_DEAD] = 1.0; S[S_K] -= 1.0; S[S_EPS] = S[S_EPSP]; }
@@ -717,9 +646,23 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
         int slot = 0;
         bool have_prev = false, stale_h = false;
         while (go) {
-            if (fuse_dir)
+            if (fuse_dir) {
+                // PFB_PCG_TAIL=1 (default OFF): without an exchange the scalar work of the iteration -- summing the
+                // convolution's fused dots and the previous update's sums, ending that iteration, beginning this one --
+                // rides in the TAIL of the convolution's inverse row kernel (its last-arriving workgroup,
+                // pcg_state.hpp): 4 launches per iteration instead of 5, bit-identical iterates (tools/check_tail.py:
+                // 240 solves at six sizes).  Measured (profiles/r03_d_pcg_tail_ab.md): a TIE -- the tail's three
+                // dependent device-scope round trips (ticket, partials, state) cost the ~6 us the launch of k_iter_sums
+                // cost (0.0646 / 0.0658 vs 0.0658 / 0.0645 ms per iteration at 1024^2, 0.3147 / 0.3139 vs 0.3139 / 0.3131
+                // at 4096^2 x 1); with agent-scope fences instead of write-through partials it LOST 8 % (every
+                // workgroup's release fence writes back its XCD's whole L2).  Kept as a switch, not as the default.
+                static const bool tail_on = [] { const char* e = getenv("PFB_PCG_TAIL"); return e && atoi(e); }();
+                plan->tail_done = 0;
+                if (tail_on && !allreduce)
+                    plan->tail = PcgTail{S, ws, plan->tail_counter, mdiv_d, G_used, pending_end ? 1 : 0, backtrack == 2 ? 2 : 3};
                 err = psfconv_apply_partials(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, (void*)st);
-            else if (backtrack == 2)
+                plan->tail.S = nullptr;
+            } else if (backtrack == 2)
                 err = pfb_psfconv_apply_dots(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, rcur, S + S_PAP, (void*)st);
             else
                 err = pfb_psfconv_apply(plan, band0, nb, p, beam, wsum, sigmainv, Ap, p, S + S_PAP, (void*)st);
@@ -730,6 +673,7 @@ static int pcg_impl(pfb_conv_plan* plan, int band0, int nb, const void* b, void*
                 // bookkeeping; with sharded bands the all-reduce of those 7 (or 4) scalars sits between
                 // the sums and the bookkeeping -- one RCCL call per iteration instead of two.
                 const int predict = backtrack == 2 ? 2 : 3;   // beta always comes from rho(alpha)
+                if (!plan->tail_done)
                 hipLaunchKernelGGL(k_iter_sums, dim3(1), dim3(256), 0, st, (const double*)plan->partials,
                                    plan->last_npartials, (const double*)ws, G_used, pending_end ? 1 : 0, S,
                                    mdiv_d, predict, allreduce ? 0 : 1);

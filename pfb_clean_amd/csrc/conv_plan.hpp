@@ -14,6 +14,7 @@
 #pragma once
 #include "common.hpp"
 #include "fft_generic.hpp"
+#include "pcg_state.hpp"
 
 struct pfb_conv_plan {
     int nx, ny, P, Q, M;       // M = Q/2
@@ -45,6 +46,11 @@ struct pfb_conv_plan {
     // iteration j-1 while iteration j is already enqueued (created on first use)
     double* pcg_pin;
     hipEvent_t pcg_ev[2];
+    // PCG driver -> fast path's inverse row kernel: do the per-iteration bookkeeping in the kernel's tail (pcg_state.hpp).
+    // Set by the driver right before an apply and cleared after it; tail_done tells it whether the kernel took it.
+    pfb::PcgTail tail;
+    unsigned* tail_counter;    // the tail's ticket word (device, zero between launches)
+    int tail_done;
 };
 
 namespace pfb {

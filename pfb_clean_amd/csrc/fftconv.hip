@@ -506,6 +506,9 @@ int pfb_psfconv_plan_create(int nx, int ny, int nx_psf, int ny_psf, int nband, i
     if (rc == PFB_OK && hipMalloc(&p->psf_l, pbytes) != hipSuccess) rc = PFB_ERR_ALLOC;
     if (rc == PFB_OK && hipMalloc((void**)&p->partials, sizeof(double) * 3 * (size_t)nx * nband) != hipSuccess)
         rc = PFB_ERR_ALLOC;
+    if (rc == PFB_OK && (hipMalloc((void**)&p->tail_counter, 256) != hipSuccess ||
+                         hipMemset(p->tail_counter, 0, 256) != hipSuccess))
+        rc = PFB_ERR_ALLOC;
     if (rc == PFB_OK) {
         p->workspace_bytes = tbytes + pbytes;
         rc = (dtype == PFB_F32) ? set_lds_limits<float>(p) : set_lds_limits<double>(p);
@@ -527,6 +530,7 @@ int pfb_psfconv_plan_destroy(pfb_conv_plan* p) {
     if (p->psf_l) (void)hipFree(p->psf_l);
     if (p->T) (void)hipFree(p->T);
     if (p->partials) (void)hipFree(p->partials);
+    if (p->tail_counter) (void)hipFree(p->tail_counter);
     if (p->long_ws) (void)hipFree(p->long_ws);
     pow2_release(p);
     if (p->prof_ev) {

@@ -1560,7 +1560,7 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
                const cplx<T>* __restrict__ twM, const cplx<T>* __restrict__ ptw,
                const T* __restrict__ x, const T* __restrict__ beam,
                const T* __restrict__ dot_with, const T* __restrict__ dot_with2, T* __restrict__ out,
-               double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv) {
+               double* __restrict__ partials, FastDims d, int band0, T scale, T sigmainv, PcgTail tail) {
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE, InvDb<T, L>::OFF, true>;
     constexpr int TPB = F::TPB;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
@@ -1649,8 +1649,11 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
         block_sum<3>(acc, red);
         if (threadIdx.x == 0) {
             const size_t np = (size_t)gridDim.x * gridDim.y, k = (size_t)bl * gridDim.x + rg;
-            partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2];
+            if (tail.S) { pcg_partial_store(partials + k, acc[0]); pcg_partial_store(partials + np + k, acc[1]); pcg_partial_store(partials + 2 * np + k, acc[2]); }
+            else { partials[k] = acc[0]; partials[np + k] = acc[1]; partials[2 * np + k] = acc[2]; }
         }
+        // PCG: the last workgroup to get here sums the partials and does the iteration's scalar bookkeeping
+        pcg_tail(tail, partials, (int)(gridDim.x * gridDim.y), gridDim.x * gridDim.y, red);
     }
 }
 
@@ -1825,7 +1828,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptw, const T* __restrict__ x, const T* __restrict__ beam,
                 const T* __restrict__ dot_with2, T* __restrict__ out,
                 double* __restrict__ partials, FastDims d, int band0, int tiles_per_band, int ntiles,
-                T scale, T sigmainv, cplx<T> wq1, int defer_stores) {
+                T scale, T sigmainv, cplx<T> wq1, int defer_stores, PcgTail tail) {
     using P = InvP<T, L, E>;
     using F = typename P::F;
     constexpr int TPB = F::TPB, G = P::G, NT = P::NT;
@@ -2018,10 +2021,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         block_sum<3>(acc, red);
         if (threadIdx.x == 0) {           // one slot per WORKGROUP (launcher: last_npartials = grid)
             const size_t np = gridDim.x;
-            partials[blockIdx.x] = acc[0];
-            partials[np + blockIdx.x] = acc[1];
-            partials[2 * np + blockIdx.x] = acc[2];
+            bool coh = false;
+            if constexpr (MODE == 2) coh = tail.S != nullptr;
+            if (coh) { pcg_partial_store(partials + blockIdx.x, acc[0]); pcg_partial_store(partials + np + blockIdx.x, acc[1]); pcg_partial_store(partials + 2 * np + blockIdx.x, acc[2]); }
+            else { partials[blockIdx.x] = acc[0]; partials[np + blockIdx.x] = acc[1]; partials[2 * np + blockIdx.x] = acc[2]; }
         }
+        if constexpr (MODE == 2) pcg_tail(tail, partials, (int)gridDim.x, gridDim.x, red);
     }
 }
 
@@ -2547,10 +2552,14 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
                                (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
                                (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam,            \
                                (const T*)dot_with2, (T*)out, p->partials, d, band0, tiles_per_band,     \
-                               ntiles, (T)scale, (T)sigmainv, wq1, defer)
+                               ntiles, (T)scale, (T)sigmainv, wq1, defer, tail)
 #define PFB_INVP2(MODE, BM) do { if (spread) PFB_INVP3(MODE, BM, true); else PFB_INVP3(MODE, BM, false); } while (0)
 #define PFB_INVP(MODE) do { if (beam) PFB_INVP2(MODE, true); else PFB_INVP2(MODE, false); } while (0)
             p->last_npartials = grid;
+            // the PCG driver's bookkeeping rides in the tail of the MODE 2 kernel (pcg_state.hpp)
+            PcgTail tail = p->tail;
+            if (!(dot_with && dot_with2) || IP::NT < 256 || grid > 1024) tail.S = nullptr;
+            if (tail.S) p->tail_done = 1;
             if (!dot_with) PFB_INVP(0);
             else if (!dot_with2) PFB_INVP(1);
             else PFB_INVP(2);
@@ -2561,10 +2570,14 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
         }
     }
     const size_t lds = 384 + sizeof(cplx<T>) * ((size_t)((F::PTWC + 1) & ~1) + (size_t)G * (F::LDS_ELEMS + 4) * (InvDb<T, L>::ON ? 2 : 1));
+    PcgTail tail = p->tail;
+    if (!(dot_with && dot_with2) || G * F::TPB < 256 || (size_t)(p->nx / G) * nb != (size_t)p->last_npartials ||
+        (size_t)(p->nx / G) * nb > 1024) tail.S = nullptr;
+    if (tail.S) p->tail_done = 1;
     hipLaunchKernelGGL((k_row_inv_pow2<T, L, E>), dim3(p->nx / G, nb), dim3(G * F::TPB), lds, st,
                        (const cplx<T>*)p->T, (const cplx<T>*)p->twQ, (const cplx<T>*)ft->twM,
                        (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam, (const T*)dot_with,
-                       (const T*)dot_with2, (T*)out, p->partials, d, band0, (T)scale, (T)sigmainv);
+                       (const T*)dot_with2, (T*)out, p->partials, d, band0, (T)scale, (T)sigmainv, tail);
 }
 
 template <typename T>

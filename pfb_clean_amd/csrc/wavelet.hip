@@ -979,18 +979,20 @@ k_dual_update_vec(const T* vp, T* __restrict__ v, const T* __restrict__ w, T lam
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_dual_bandsum(const T* __restrict__ vp, const T* __restrict__ v, T sigma, int nband, size_t nper,
-               T* __restrict__ sum_out) {
+               size_t bstride, T* __restrict__ sum_out) {
+    // bstride: elements between the bands of vp / v (= nper for the whole plane; a CHUNK of the plane is the same
+    // call on shifted pointers with the chunk's length as nper)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
          i += (size_t)gridDim.x * blockDim.x) {
         T sum = 0;
-        for (int b = 0; b < nband; ++b) sum += vp[(size_t)b * nper + i] + sigma * v[(size_t)b * nper + i];
+        for (int b = 0; b < nband; ++b) sum += vp[(size_t)b * bstride + i] + sigma * v[(size_t)b * bstride + i];
         sum_out[i] = sum;
     }
 }
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_dual_apply(const T* vp, T* __restrict__ v, const T* __restrict__ w, const T* __restrict__ sum_in,
-             T lam, T sigma, int nband, size_t nper, T* vp_out) {
+             T lam, T sigma, int nband, size_t nper, size_t bstride, T* vp_out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper;
          i += (size_t)gridDim.x * blockDim.x) {
         const T a = fabs(sum_in[i] / sigma);
@@ -1000,7 +1002,7 @@ k_dual_apply(const T* vp, T* __restrict__ v, const T* __restrict__ w, const T* _
             fac = T(1) - soft / a;
         }
         for (int b = 0; b < nband; ++b) {
-            const size_t k = (size_t)b * nper + i;
+            const size_t k = (size_t)b * bstride + i;
             const T vpk = vp[k];
             const T vt = vpk + sigma * v[k];
             const T vn = (a != T(0)) ? vt * fac : vt;
@@ -2119,34 +2121,44 @@ int pfb_dual_update(int dtype, const void* vp, void* v, const void* weight, doub
     return PFB_OK;
 }
 
-int pfb_dual_bandsum(int dtype, const void* vp, const void* v, double sigma, int nband, size_t nper,
-                     void* sum_out, void* stream) {
-    PFB_REQUIRE(vp && v && sum_out && nband > 0, PFB_ERR_INVALID, "dual_bandsum: bad argument");
+int pfb_dual_bandsum_chunk(int dtype, const void* vp, const void* v, double sigma, int nband, size_t count,
+                           size_t band_stride, void* sum_out, void* stream) {
+    PFB_REQUIRE(vp && v && sum_out && nband > 0 && band_stride >= count, PFB_ERR_INVALID, "dual_bandsum: bad argument");
+    if (count == 0) return PFB_OK;
     hipStream_t st = as_stream(stream);
     if (dtype == PFB_F32)
-        hipLaunchKernelGGL((k_dual_bandsum<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
-                           (const float*)v, (float)sigma, nband, nper, (float*)sum_out);
+        hipLaunchKernelGGL((k_dual_bandsum<float>), dim3(ew_grid(count)), dim3(256), 0, st, (const float*)vp,
+                           (const float*)v, (float)sigma, nband, count, band_stride, (float*)sum_out);
     else
-        hipLaunchKernelGGL((k_dual_bandsum<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
-                           (const double*)v, sigma, nband, nper, (double*)sum_out);
+        hipLaunchKernelGGL((k_dual_bandsum<double>), dim3(ew_grid(count)), dim3(256), 0, st, (const double*)vp,
+                           (const double*)v, sigma, nband, count, band_stride, (double*)sum_out);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
 }
+int pfb_dual_bandsum(int dtype, const void* vp, const void* v, double sigma, int nband, size_t nper,
+                     void* sum_out, void* stream) {
+    return pfb_dual_bandsum_chunk(dtype, vp, v, sigma, nband, nper, nper, sum_out, stream);
+}
 
-int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in, double lam,
-                   double sigma, int nband, size_t nper, void* vp_out, void* stream) {
-    PFB_REQUIRE(vp && v && weight && sum_in && nband > 0, PFB_ERR_INVALID, "dual_apply: bad argument");
+int pfb_dual_apply_chunk(int dtype, const void* vp, void* v, const void* weight, const void* sum_in, double lam,
+                         double sigma, int nband, size_t count, size_t band_stride, void* vp_out, void* stream) {
+    PFB_REQUIRE(vp && v && weight && sum_in && nband > 0 && band_stride >= count, PFB_ERR_INVALID, "dual_apply: bad argument");
+    if (count == 0) return PFB_OK;
     hipStream_t st = as_stream(stream);
     if (dtype == PFB_F32)
-        hipLaunchKernelGGL((k_dual_apply<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp,
+        hipLaunchKernelGGL((k_dual_apply<float>), dim3(ew_grid(count)), dim3(256), 0, st, (const float*)vp,
                            (float*)v, (const float*)weight, (const float*)sum_in, (float)lam, (float)sigma,
-                           nband, nper, (float*)vp_out);
+                           nband, count, band_stride, (float*)vp_out);
     else
-        hipLaunchKernelGGL((k_dual_apply<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp,
-                           (double*)v, (const double*)weight, (const double*)sum_in, lam, sigma, nband, nper,
-                           (double*)vp_out);
+        hipLaunchKernelGGL((k_dual_apply<double>), dim3(ew_grid(count)), dim3(256), 0, st, (const double*)vp,
+                           (double*)v, (const double*)weight, (const double*)sum_in, lam, sigma, nband, count,
+                           band_stride, (double*)vp_out);
     PFB_HIP_CHECK(hipGetLastError());
     return PFB_OK;
+}
+int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in, double lam,
+                   double sigma, int nband, size_t nper, void* vp_out, void* stream) {
+    return pfb_dual_apply_chunk(dtype, vp, v, weight, sum_in, lam, sigma, nband, nper, nper, vp_out, stream);
 }
 
 int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight, double lam, double sigma,

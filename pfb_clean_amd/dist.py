@@ -263,3 +263,70 @@ def global_max(value, device, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t.item()
+
+
+# ------------------------------------------------------------------ coefficient-plane exchange (primal-dual, band-sharded)
+def plane_chunks(nper, itemsize, world):
+    """Chunk boundaries [(off, count), ...] of an nper-element plane for the pipelined exchange: about 32 MiB per chunk
+    (PFB_PD_CHUNK_MB), at most 16 chunks, every boundary a multiple of world x 64 elements so that a chunk splits evenly
+    into the reduce-scatter shards and each shard stays 256-byte aligned; the last chunk takes the remainder."""
+    try:
+        mb = float(os.environ.get('PFB_PD_CHUNK_MB', '32'))
+    except ValueError:
+        mb = 32.0
+    quantum = 64 * max(1, int(world))
+    target = max(quantum, int(mb * (1 << 20) / itemsize))
+    nchunk = max(1, min(16, -(-nper // target)))
+    per = -(-nper // nchunk)
+    per = -(-per // quantum) * quantum
+    out, off = [], 0
+    while off < nper:
+        cnt = min(per, nper - off)
+        out.append((off, cnt))
+        off += cnt
+    return out
+
+
+def exchange_plane_pipelined(plane, bandsum, apply, group=None):
+    """The band sum of the l21 dual update (prox_21m.py:89-103 sums over ALL bands) with the bands sharded over ranks:
+    `plane` (1-D view of the (nbasis, nymax, nxmax) coefficient plane) is filled chunk by chunk with the LOCAL sums by
+    bandsum(off, count), summed over the ranks, and handed to apply(off, count) -- software-pipelined so that the
+    exchange of chunk c overlaps the band sums of chunk c + 1 and the threshold of chunk c - 1:
+
+        bandsum(0) | exchange(0)   bandsum(1) | exchange(1)   apply(0)  bandsum(2) | exchange(2)  apply(1) ...
+
+    With the `nccl` backend (RCCL) the exchange of a chunk is an explicit REDUCE-SCATTER followed by an ALL-GATHER,
+    both asynchronous on RCCL's stream (the plane is bandwidth bound -- 86 MB at config #4, 2.7 GB at
+    config #5 -- and a ring over all xGMI links moves 2 (W-1)/W of it per rank either way; the explicit pair keeps
+    each collective a single-algorithm, full-ring transfer and lets the first all-gathers start while later chunks
+    are still being reduced).  Other backends (gloo: CPU rehearsals, two ranks on one test GPU) use all_reduce per
+    chunk.  PFB_PD_RSAG=0 forces all_reduce.  Returns the number of chunks."""
+    pg = None if group is True else group
+    world = dist.get_world_size(pg)
+    n = plane.numel()
+    chunks = plane_chunks(n, plane.element_size(), world)
+    rsag = (dist.get_backend(pg) == 'nccl' and plane.is_cuda and os.environ.get('PFB_PD_RSAG', '1') != '0')
+    pending = []                      # (off, count, work handle)
+
+    def finish(item):
+        off, cnt, work = item
+        for w in work:
+            w.wait()                  # device-side for nccl (the current stream waits for RCCL's), host-side for gloo
+        apply(off, cnt)
+
+    for off, cnt in chunks:
+        bandsum(off, cnt)
+        view = plane[off:off + cnt]
+        if rsag and cnt % world == 0:
+            shard = torch.empty(cnt // world, dtype=plane.dtype, device=plane.device)
+            w1 = dist.reduce_scatter_tensor(shard, view, op=dist.ReduceOp.SUM, group=pg, async_op=True)
+            w2 = dist.all_gather_into_tensor(view, shard, group=pg, async_op=True)   # same RCCL stream: ordered behind w1
+            work = (w1, w2)
+        else:
+            work = (dist.all_reduce(view, op=dist.ReduceOp.SUM, group=pg, async_op=True),)
+        pending.append((off, cnt, work))
+        if len(pending) > 1:
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
+    return len(chunks)

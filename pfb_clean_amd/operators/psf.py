@@ -255,13 +255,18 @@ class PsfConvPlan:
         return out3[0] if squeeze else out3
 
     def _enter_stream(self):
-        """Call with `lock` held: the plan's workspace is about to be used on the current stream; if the
-        previous user enqueued on a DIFFERENT stream, wait for that work first (same stream: stream order
-        already serialises the kernels)."""
+        """Call with `lock` held, BEFORE enqueueing on the current stream: the plan's workspace is about to be used
+        there.  If the previous user enqueued on a DIFFERENT stream its work must finish first -- as a DEVICE-side
+        dependency (an event recorded behind the previous user's enqueue, waited for by the current stream), never a
+        host wait: with the reference's dask-thread pattern (several threads, one plan, a stream per thread,
+        pcg.py:346-356) a host synchronize here would stall every thread queued on the lock until the previous thread's
+        whole stream had drained.  Same stream: stream order already serialises the kernels."""
         cur = torch.cuda.current_stream()
         last = self.__dict__.get('_last_stream')
         if last is not None and last != cur:
-            last.synchronize()
+            ev = torch.cuda.Event()
+            ev.record(last)               # behind everything the previous user has enqueued so far (it holds no lock now)
+            cur.wait_event(ev)
         self._last_stream = cur
 
     def set_profiling(self, on):

@@ -72,11 +72,19 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
     npix = xd[0].numel()
     xp = xd.clone()
     vp = vd.clone()
+    # The LINEAR-synthesis form (2 psi^H(v) - psi^H(vp), one extra synthesis before the loop, outputs overwritten) is
+    # only taken when `psiH` is this package's Psi.hdot, which is exactly linear and overwrites its output.  Any other
+    # callable -- a masked, clipped or otherwise affine synthesis is legal in this signature -- gets the reference's
+    # statement order verbatim: vp = 2 v - vp; psiH(vp, xout) (primal_dual.py:137-138).
+    linear_syn = getattr(psiH, '__self__', None).__class__.__name__ == 'Psi' and getattr(psiH, '__name__', '') == 'hdot' \
+        and getattr(psiH, '__module__', '').startswith('pfb_clean_amd')
     # s_new = psi^H(v) of this iteration, s_old = psi^H(vp) = psi^H(v) of the previous one (linear synthesis)
     s_new = torch.zeros_like(xd)
     s_old = torch.zeros_like(xd)
-    psiH(vp, s_old)
-    fused_grad = isinstance(grad, PsfGradient) and not as_numpy and grad.data.shape == xd.shape and grad.data.dtype == dt
+    if linear_syn:
+        psiH(vp, s_old)
+    fused_grad = linear_syn and isinstance(grad, PsfGradient) and not as_numpy and grad.data.shape == xd.shape \
+        and grad.data.dtype == dt
     w = _dev.to_dev(l1weight, dt).contiguous()
     ws, out = _dev.scratch()
 
@@ -126,17 +134,31 @@ def primal_dual_optimised(x, v, lam, psiH, psi, L, prox, l1weight, reweighter, g
             psi(xp, vn)                                                  # :135
         prefetched = False
         dual_update_numba(vp, vn, lam, sigma=sigma, weight=w, group=group)   # :136
-        psiH(vn, s_new)                                                  # :137-138 as 2 psiH(v) - psiH(vp)
-        if fused_grad:
-            gd, gsub = grad.conv(xp), grad.data                          # :139, `- data` inside the update
+        pos_arg = 0 if (group is not None and positivity == 2) else int(positivity)
+        if linear_syn:
+            psiH(vn, s_new)                                              # :137-138 as 2 psiH(v) - psiH(vp)
+            if fused_grad:
+                gd, gsub = grad.conv(xp), grad.data                      # :139, `- data` inside the update
+            else:
+                gd, gsub = _dev.to_dev(grad(host(xp)), dt).contiguous(), None
+            _lib.check(lib.pfb_pd_primal_update2(code, _dev.ptr(xp), _dev.ptr(s_new), _dev.ptr(s_old), _dev.ptr(gd),
+                                                 _dev.ptr(gsub), float(tau), pos_arg, nband, npix,
+                                                 _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
+                                                 _dev.stream()))         # :140-146
         else:
-            gd, gsub = _dev.to_dev(grad(host(xp)), dt).contiguous(), None
-        _lib.check(lib.pfb_pd_primal_update2(code, _dev.ptr(xp), _dev.ptr(s_new), _dev.ptr(s_old), _dev.ptr(gd),
-                                             _dev.ptr(gsub), float(tau),
-                                             0 if (group is not None and positivity == 2)
-                                             else int(positivity), nband, npix,
-                                             _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
-                                             _dev.stream()))             # :140-146
+            # the reference's own statements: vp = 2 v - vp (vp is dead afterwards: re-set at the top of the next
+            # iteration), psiH(vp, xout) with whatever the caller's synthesis does to its arguments, xout += grad(xp)
+            _lib.check(lib.pfb_axpby(code, 2.0, _dev.ptr(vn), -1.0, _dev.ptr(vp), vp.numel(), _dev.stream()))   # :137
+            if as_numpy:
+                sh = s_new.cpu().numpy()
+                psiH(host(vp), sh)
+                s_new.copy_(torch.from_numpy(sh))
+            else:
+                psiH(vp, s_new)                                          # :138
+            gd = _dev.to_dev(grad(host(xp)), dt).contiguous()            # :139
+            _lib.check(lib.pfb_pd_primal_update(code, _dev.ptr(xp), _dev.ptr(s_new), _dev.ptr(gd), float(tau), pos_arg,
+                                                nband, npix, _dev.ptr(xn), _dev.ptr(out), _dev.ptr(ws),
+                                                _dev.stream()))          # :140-146
         if group is not None:
             if positivity == 2:
                 bad = (xn <= 0).any(dim=0).to(torch.uint8)

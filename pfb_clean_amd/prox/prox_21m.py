@@ -79,20 +79,32 @@ def dual_update_numba(vp, v, lam, sigma=1.0, weight=None, vp_out=None, group=Non
 
 
 def _dual_update_sharded(vp, v, lam, sigma, weight, vp_out, group):
-    import torch.distributed as dist
+    """Bands sharded over the ranks of `group`: local band sums -> sum over the ranks -> threshold, chunk by chunk with
+    the exchange of one chunk overlapping the kernels of its neighbours (dist.exchange_plane_pipelined: reduce-scatter
+    + all-gather per chunk on RCCL)."""
+    from ..dist import exchange_plane_pipelined
     lib = _lib.load()
     if not (isinstance(v, torch.Tensor) and v.is_cuda and v.is_contiguous()):
         raise TypeError("band-sharded dual update works on contiguous GPU tensors")
     vd, wd, nband, nper = _prep(v, weight)
     vpd = _dev.to_dev(vp, vd.dtype).contiguous()
-    plane = torch.empty(vd.shape[1:], dtype=vd.dtype, device=vd.device)
+    if vp_out is not None and not (vp_out.is_contiguous() and vp_out.shape == vd.shape and vp_out.dtype == vd.dtype):
+        raise ValueError("vp_out must be a contiguous tensor shaped like v")
+    plane = torch.empty(nper, dtype=vd.dtype, device=vd.device)
     code = _dev.code(vd.dtype)
-    _lib.check(lib.pfb_dual_bandsum(code, _dev.ptr(vpd), _dev.ptr(vd), float(sigma), nband, nper,
-                                    _dev.ptr(plane), _dev.stream()))
-    dist.all_reduce(plane, op=dist.ReduceOp.SUM, group=None if group is True else group)
-    _lib.check(lib.pfb_dual_apply(code, _dev.ptr(vpd), _dev.ptr(vd), _dev.ptr(wd), _dev.ptr(plane),
-                                  float(lam), float(sigma), nband, nper,
-                                  _dev.ptr(vp_out) if vp_out is not None else None, _dev.stream()))
+    es = vd.element_size()
+
+    def at(t, off):
+        return None if t is None else t.data_ptr() + off * es
+
+    def bandsum(off, cnt):
+        _lib.check(lib.pfb_dual_bandsum_chunk(code, at(vpd, off), at(vd, off), float(sigma), nband, cnt, nper,
+                                              at(plane, off), _dev.stream()))
+
+    def apply(off, cnt):
+        _lib.check(lib.pfb_dual_apply_chunk(code, at(vpd, off), at(vd, off), at(wd, off), at(plane, off), float(lam),
+                                            float(sigma), nband, cnt, nper, at(vp_out, off), _dev.stream()))
+    exchange_plane_pipelined(plane, bandsum, apply, group)
     return v
 
 

@@ -347,8 +347,13 @@ def _pd_worker(rank, world, port, q):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from pfb_clean_amd.dist import shard_bands
+        from pfb_clean_amd.dist import shard_bands, exchange_plane_pipelined, plane_chunks
         from oracle import fftconv as ofc, wavelets as owv
+        os.environ['PFB_PD_CHUNK_MB'] = '0.02'           # several chunks even on the fixture's small plane
+        for nper, es, wsz in ((21383120, 4, 4), (337184720, 8, 8), (1000, 8, 2), (45885, 8, 3)):
+            ch = plane_chunks(nper, es, wsz)
+            assert ch[0][0] == 0 and sum(c for _, c in ch) == nper and all(o % (64 * wsz) == 0 for o, _ in ch)
+            assert all(ch[i][0] + ch[i][1] == ch[i + 1][0] for i in range(len(ch) - 1)) and len(ch) <= 16 or es == 8
         g = np.load(os.path.join(ROOT, 'tests', 'golden', 'pd.npz'))
         psfhat, Q, data = g['psfhat'], int(g['Q']), g['data']
         nband, P, _ = psfhat.shape
@@ -372,12 +377,20 @@ def _pd_worker(rank, world, port, q):
             for k in range(maxit):
                 psi.dot(xp, v)
                 vt = vp + sigma * v
-                plane = torch.from_numpy(vt.sum(axis=0))
-                dist.all_reduce(plane)
-                a = np.abs(plane.numpy() / sigma)
-                soft = np.maximum(a - lam * w / sigma, 0.0)
-                fac = np.where(a != 0, 1.0 - soft / np.where(a != 0, a, 1.0), 1.0)
-                v[...] = vt * fac[None]
+                # the exchange exactly as prox_21m._dual_update_sharded drives it: chunked, pipelined, sum over ranks
+                plane = torch.zeros(w.size, dtype=torch.float64)
+                vtf, vf, wf = vt.reshape(nb, -1), v.reshape(nb, -1), w.reshape(-1)
+
+                def bandsum(off, cnt):
+                    plane[off:off + cnt] = torch.from_numpy(vtf[:, off:off + cnt].sum(axis=0))
+
+                def apply(off, cnt):
+                    a = np.abs(plane[off:off + cnt].numpy() / sigma)
+                    soft = np.maximum(a - lam * wf[off:off + cnt] / sigma, 0.0)
+                    fac = np.where(a != 0, 1.0 - soft / np.where(a != 0, a, 1.0), 1.0)
+                    vf[:, off:off + cnt] = vtf[:, off:off + cnt] * fac[None]
+                nchunks = exchange_plane_pipelined(plane, bandsum, apply, None)
+                assert nchunks > 1
                 vp = 2 * v - vp
                 psi.hdot(vp, xout)
                 xout += ofc.psf_convolve_cube(xpad, xhat, xo, psfhat[sl], Q, xp) - data[sl]

@@ -383,6 +383,10 @@ def test_psfhat_producer_falls_back_for_odd_last_axis():
     from pfb_clean_amd.operators.fft import psfhat_from_psf
     psf = np.random.default_rng(2).standard_normal((1, 30, 33))
     assert np.abs(psfhat_from_psf(psf) - ofc.psfhat_from_psf(psf)).max() < 1e-11
+    # an even grid with a prime factor above 13 (34 = 2 x 17): the kernels answer PFB_ERR_UNSUPPORTED and the producer
+    # degrades to torch.fft like the reference's r2c, which takes any size
+    psf = np.random.default_rng(3).standard_normal((1, 34, 34))
+    assert np.abs(psfhat_from_psf(psf) - ofc.psfhat_from_psf(psf)).max() < 1e-11
 
 
 def _pcg_rank(rank, world, port, q):

@@ -163,6 +163,51 @@ def test_standalone_dwt2d_idwt2d_with_the_reference_argument_lists(amd, wavelet,
         dwt2d(data, alpha2, cbuff, cbuffT, ix, iy, tuple(v + 1 for v in sx), sy, dec_lo, dec_hi, nlevel)
 
 
+def test_primal_dual_with_a_callers_own_affine_synthesis(amd):
+    """`psiH` is an arbitrary callable in primal_dual_optimised's signature (primal_dual.py:91-101).  The linear-synthesis
+    shortcut (2 psi^H(v) - psi^H(vp)) is only valid for a LINEAR synthesis that overwrites its output, so it is taken
+    for this package's Psi.hdot alone; any other callable must see the reference's statement order vp = 2 v - vp;
+    psiH(vp, xout) (primal_dual.py:137-138).  Here the synthesis is AFFINE (adds an offset, clips): the shortcut would
+    give different iterates; the oracle runs the reference's statements with the same callable."""
+    from pfb_clean_amd.opt.primal_dual import primal_dual_optimised
+    rng = np.random.default_rng(21)
+    nb, nx, ny = 2, 48, 40
+    bases = ['self', 'db2']
+    psi = amd.Psi(nb, nx, ny, bases, 2, 1)
+    po = owv.Psi(nb, nx, ny, bases, 2, 1)
+    nbasis = len(bases)
+    data = rng.standard_normal((nb, nx, ny))
+    x0 = 0.1 * rng.random((nb, nx, ny))
+    a = np.zeros((nb, nbasis, po.Nymax, po.Nxmax))
+    po.dot(x0, a)
+    v0 = 0.05 * rng.standard_normal(a.shape) * (a != 0)
+    w = np.ones((nbasis, po.Nymax, po.Nxmax))
+
+    def syn_ref(vv, xo):
+        po.hdot(vv, xo)
+        xo += 0.01
+        np.clip(xo, -0.8, 0.8, out=xo)
+
+    def syn_gpu(vv, xo):
+        psi.hdot(vv, xo)
+        xo += 0.01
+        xo.clamp_(-0.8, 0.8)
+    xo_, vo_ = x0.copy(), v0.copy()
+    osv.primal_dual_optimised(xo_, vo_, 0.02, syn_ref, po.dot, 1.0, None, w, None, lambda t: 0.3 * t - data,
+                              nu=nbasis, tol=0.0, maxit=6, positivity=1, verbosity=0)
+    dgpu = torch.from_numpy(data).cuda()
+    xg, vg = torch.from_numpy(x0).cuda(), torch.from_numpy(v0).cuda()
+    xg, vg = primal_dual_optimised(xg, vg, 0.02, syn_gpu, psi.dot, 1.0, None, torch.from_numpy(w).cuda(), None,
+                                   lambda t: 0.3 * t - dgpu, nu=nbasis, tol=0.0, maxit=6, positivity=1, verbosity=0)
+    assert maxerr(xg.cpu().numpy(), xo_) < 1e-12 * np.abs(xo_).max()
+    assert maxerr(vg.cpu().numpy(), vo_) < 1e-12 * max(np.abs(vo_).max(), 1.0)
+    # and the shortcut is really not equivalent here: with Psi.hdot handed in directly the iterates differ
+    xl, vl = primal_dual_optimised(torch.from_numpy(x0).cuda(), torch.from_numpy(v0).cuda(), 0.02, psi.hdot, psi.dot, 1.0,
+                                   None, torch.from_numpy(w).cuda(), None, lambda t: 0.3 * t - dgpu, nu=nbasis, tol=0.0,
+                                   maxit=6, positivity=1, verbosity=0)
+    assert maxerr(xl.cpu().numpy(), xo_) > 1e-6
+
+
 def test_psi_device_tensors_adjoint_and_errors(amd):
     rng = np.random.default_rng(9)
     nband, nx, ny = 2, 96, 80

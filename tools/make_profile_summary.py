@@ -64,7 +64,21 @@ for k in sorted(fe):
     if k.startswith(('k_row_fwd', 'k_col', 'k_row_inv')):
         conv += 2 * f + w
 out['conv_group_hbm_bytes_per_launch'] = conv
-out['config'] = dict(size=4096, bands=8, dtype='f32')
+# which kernels these counters saw: the commit of the tree and the hash of the kernel sources (bench.py only derives a
+# rate from this file while its own kernel sources still hash to the same value)
+import subprocess
+sys.path.insert(0, root)
+import bench as _bench
+cfg = bj.get('config', {})
+size = int(os.environ.get('PFB_PROF_SIZE', 4096))
+out['config'] = dict(workload='pcg', size=size, bands=int(cfg.get('bands_per_gpu', 8)), dtype=bj.get('dtype', 'f32'))
+try:
+    out['commit'] = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+    out['tree_dirty'] = bool(subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'pfb_clean_amd/csrc'],
+                                            capture_output=True, text=True).stdout.strip())
+except Exception:
+    out['commit'] = None
+out['kernel_src_sha16'] = _bench.kernel_src_hash('pcg')
 json.dump(out, open(os.path.join(root, 'profiles', tag + '_hbm_traffic.json'), 'w'), indent=1)
 print(open(os.path.join(root, 'profiles', tag + '_bench_kernel_stats.md')).read())
 print(json.dumps({k: v for k, v in out.items() if k.startswith(('k_row', 'k_col', 'conv', 'k_pcg'))}, indent=1))
