@@ -185,6 +185,21 @@ __device__ __forceinline__ int launder(int v) {
     return v;
 }
 
+// exp(-2 pi i k / 32) for the kernels that rebuild a long twiddle table from a short one: w^(t + c j) = w^t x (a 32nd root
+// of unity that is a compile-time constant once the loop over j is unrolled)
+template <typename T>
+__device__ __forceinline__ cplx<T> root32(int k) {              // exp(-2 pi i k / 32); folds to constants for constant k
+    constexpr T C[9] = {T(1), T(0.98078528040323044912618223613423903697L), T(0.92387953251128675612818318939678828682L),
+                        T(0.83146961230254523707878837761790575673L), T(0.70710678118654752440084436210484903928L),
+                        T(0.55557023301960222474283081394853287438L), T(0.38268343236508977172845998403039886676L),
+                        T(0.19509032201612826784828486847702224093L), T(0)};
+    auto cs = [&](int q) -> T {                                 // cos(2 pi q / 32)
+        q &= 31;
+        return q <= 8 ? C[q] : q <= 16 ? -C[16 - q] : q <= 24 ? -C[q - 16] : C[32 - q];
+    };
+    return cplx<T>(cs(k), -cs(k - 8));
+}
+
 // XCD-aware row-group order of the plain row kernels.  A workgroup of G rows touches T in G x 16-byte pieces; 8 rows
 // make a 128-byte line.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2), so the
 // SH = 8 / G row groups of one line are given to blocks b, b + 8, .. b + 8 (SH - 1): their pieces meet in ONE L2 and
@@ -624,19 +639,6 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 // kernel: five).  The twiddles w_P^n, n = t + TPB j, are w_P^t (LDS table of TPB entries) times the compile-time
 // constants exp(-2 pi i j / 4E).  The PSF spectrum is stored class-major for this kernel (psf_l[blk][r][m][c] =
 // psfhat[4 m + r], see psf_off), so that every slice is a contiguous 16-byte-per-lane stream.
-template <typename T>
-__device__ __forceinline__ cplx<T> root32(int k) {              // exp(-2 pi i k / 32); folds to constants for constant k
-    constexpr T C[9] = {T(1), T(0.98078528040323044912618223613423903697L), T(0.92387953251128675612818318939678828682L),
-                        T(0.83146961230254523707878837761790575673L), T(0.70710678118654752440084436210484903928L),
-                        T(0.55557023301960222474283081394853287438L), T(0.38268343236508977172845998403039886676L),
-                        T(0.19509032201612826784828486847702224093L), T(0)};
-    auto cs = [&](int q) -> T {                                 // cos(2 pi q / 32)
-        q &= 31;
-        return q <= 8 ? C[q] : q <= 16 ? -C[16 - q] : q <= 24 ? -C[q - 16] : C[32 - q];
-    };
-    return cplx<T>(cs(k), -cs(k - 8));
-}
-
 template <typename T, int H, int E>
 struct ColX {
     static constexpr int HS = H / 2;
@@ -1069,18 +1071,28 @@ k_row_fwd_pow2(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __r
 // (static store count -> the compiler's vmcnt for the prefetched rows is exact).
 template <typename T, int L>
 struct FwdP {
-    static constexpr int E = L / 128;                 // 128 threads per row, 8 rows per workgroup
+    // 128 threads per row, 8 rows per workgroup -- and for the 4096-point rows of 8192-pixel lines (BIG) 256 threads per
+    // row, 4 rows (64-byte pieces, XCD-paired to full lines), with the twiddle table w_M^n cut down to the 512 entries a
+    // sweep step spans (SMT): the full table (32 KB) does not fit next to four 4096-point rows.  Both transforms use 16
+    // elements per thread, and with M = 2 L = 32 TPB every other twiddle is a table entry times a 32nd root of unity:
+    //     w_M^(t + TPB j)      = w_M^t       root32(j)        (odd-bin pre-multiply, j = register index)
+    //     w_M^(m0 + h + MS K)  = w_M^(m0+h)  root32(2 K)      (sweep step K, MS = NVB BSTEP = M / 16)
+    static constexpr bool BIG = L >= 4096;
+    static constexpr int E = BIG ? 16 : L / 128;
     static constexpr int EOK = (E == 8 || E == 16) ? E : 8;
     using F = RegFft<T, L, EOK, false, 0, true, true>;
-    static constexpr int G = 8;
+    static constexpr int TPR = L / EOK;               // threads per row
     static constexpr int NT = 1024;
+    static constexpr int G = NT / TPR;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
     static constexpr int NBE = (L + NVB) / NVB;
     static constexpr int NBO = L / NVB;
     static constexpr int BSTEP = NT / G;
+    static constexpr bool SMT = BIG;
+    static constexpr int NTM = SMT ? NVB * BSTEP : L; // entries of the w_M table kept in the LDS
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
-    static constexpr size_t LDS = sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE);
+    static constexpr size_t LDS = sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE);
     // (an fp64 version with two-row 512-thread tiles -- what the LDS allows -- writes 32-byte pieces and
     // measured 0.90 vs 0.54 ms for the plain kernel: not used)
     // measured: 0.50 -> 0.42 ms at ny = 4096 (x 8 bands of 4096 rows); at ny = 2048 the plain
@@ -1089,7 +1101,25 @@ struct FwdP {
                              // 0.0633 (sequential parities) / 0.0677 ms against 0.0561 ms for the plain kernel at 2048^2 x 4
 #define PFB_FWDP_E8 0
 #endif
-    static constexpr bool OK = (E == 16 || (PFB_FWDP_E8 && E == 8 && sizeof(T) == 4)) && LDS <= (size_t)160 * 1024;
+    static constexpr bool OK = (E == 16 || (PFB_FWDP_E8 && E == 8 && sizeof(T) == 4)) && LDS <= (size_t)160 * 1024 &&
+                               (!SMT || (EOK == 16 && 32 * TPR == 2 * L && 16 * NVB * BSTEP == 2 * L));
+    // w_M^(t + TPR j) from the table in the LDS
+    __device__ __forceinline__ static cplx<T> tw_row(const cplx<T>* ltm, int t, int j) {
+        if constexpr (SMT) return j == 0 ? ltm[t] : ltm[t] * root32<T>(j);
+        else return ltm[t + TPR * j];
+    }
+    // tile v of a band -> first row: G < 8 rows make G x 16-byte pieces of T; tiles b and b + 8 (dealt to the same XCD,
+    // hence one L2) take the pieces of ONE 128-byte line (cf. k_row_inv_pow2p)
+    __device__ __forceinline__ static int tile_row(int rg, int tiles_per_band) {
+        constexpr int SH = 8 / G;
+        if constexpr (SH > 1) {
+            if (tiles_per_band % (8 * SH) == 0) {
+                const int q = rg / (8 * SH), rem = rg % (8 * SH);
+                rg = SH * (q * 8 + (rem & 7)) + (rem >> 3);
+            }
+        }
+        return rg * G;
+    }
 };
 
 template <typename T, int L, int PAR, int K, int NIT, typename Hook>
@@ -1171,7 +1201,9 @@ __device__ __forceinline__ void post_steps_lin(const cplx<T>* const (&za)[FastCf
         Blk<T, NVB> o;
 #pragma unroll
         for (int h = 0; h < NVB; ++h) {
-            cplx<T> w = lw[MS * K + h];
+            cplx<T> w;
+            if constexpr (P::SMT) w = K == 0 ? lw[h] : lw[h] * root32<T>(2 * K);      // w_M^(m0 + h + MS K), MS = M / 16
+            else w = lw[MS * K + h];
             if (PAR) w = w * wq1;
             const cplx<T> zv = za[h][F::cpad(MS * K)];
             cplx<T> zm = zb[h][F::cpad(MS * (NREG - 1 - K))];
@@ -1238,14 +1270,14 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
     cplx<T>* ltm = ltw + P::PTWP;
-    cplx<T>* lds0 = ltm + L;
+    cplx<T>* lds0 = ltm + P::NTM;
     int vb = blockIdx.x;
     if (vb >= ntiles) return;
     for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptwc[k];
-    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    for (int k = threadIdx.x; k < P::NTM; k += NT) ltm[k] = twM[k];
     V2 xa[E], ba[BEAM ? E : 1];
     {
-        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int bl = vb / tiles_per_band, i0 = P::tile_row(vb - bl * tiles_per_band, tiles_per_band);
         const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
         const size_t off = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
         const V2* xr = reinterpret_cast<const V2*>(x + off) + t;
@@ -1261,7 +1293,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     for (int sit = 0;; ++sit) {
         STAMP(0, sit, 0);
         const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
-        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int bl = vb / tiles_per_band, i0 = P::tile_row(vb - bl * tiles_per_band, tiles_per_band);
         cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
         cplx<T> vv[2][E];
         {
@@ -1273,7 +1305,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
                 V2 a = xa[j];
                 if constexpr (BEAM) { a.x *= ba[j].x; a.y *= ba[j].y; }
                 vv[0][j] = cplx<T>(a.x, a.y);                    // z[n] = x[2n] + i x[2n+1]
-                vv[1][j] = vv[0][j] * ltm[t + TPB * j];          // z .* w_M^n  (odd bins)
+                vv[1][j] = vv[0][j] * P::tw_row(ltm, t, j);      // z .* w_M^n  (odd bins)
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
             STAMP(0, sit, 1);
@@ -1289,7 +1321,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             for (int j = 0; j < E; ++j) wp[F::cpad(TPB * j)] = vv[0][j];
             // next tile's rows: in flight during both post-processing sweeps
             if constexpr (!SPR) {
-                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const int bln = vbn / tiles_per_band, i0n = P::tile_row(vbn - bln * tiles_per_band, tiles_per_band);
                 const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
 #pragma unroll
                 for (int j = 0; j < E; ++j) xa[j] = xr[TPB * j];
@@ -1302,7 +1334,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             const int tid = launder((int)threadIdx.x);
             if constexpr (SPR) {
                 const int g = tid / TPB, t = tid % TPB;
-                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const int bln = vbn / tiles_per_band, i0n = P::tile_row(vbn - bln * tiles_per_band, tiles_per_band);
                 const V2* xr = reinterpret_cast<const V2*>(x + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
                 fwdp_post<T, L, 0>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G,
                                    [&](auto k) {
@@ -1318,7 +1350,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
         if constexpr (BEAM && !SPR) {   // the next tile's beam rows: requested once the even-bin registers are free
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB;
-            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+            const int bln = vbn / tiles_per_band, i0n = P::tile_row(vbn - bln * tiles_per_band, tiles_per_band);
             const V2* br = reinterpret_cast<const V2*>(beam + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
 #pragma unroll
             for (int j = 0; j < E; ++j) ba[j] = br[TPB * j];
@@ -1333,7 +1365,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             __syncthreads();
             STAMP(0, sit, 5);
             if constexpr (BEAM && SPR) {
-                const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+                const int bln = vbn / tiles_per_band, i0n = P::tile_row(vbn - bln * tiles_per_band, tiles_per_band);
                 const V2* br = reinterpret_cast<const V2*>(beam + (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch) + t;
                 fwdp_post<T, L, 1>(lds0 + (size_t)(tid % G) * P::STRIDE, ltm, wq1, Tb, d.nx, i0, tid % G, tid / G,
                                    [&](auto k) {
@@ -1376,14 +1408,14 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem);
     cplx<T>* ltm = ltw + P::PTWP;
-    cplx<T>* lds0 = ltm + L;
+    cplx<T>* lds0 = ltm + P::NTM;
     int vb = blockIdx.x;
     if (vb >= ntiles) return;
     for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptwc[k];
-    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    for (int k = threadIdx.x; k < P::NTM; k += NT) ltm[k] = twM[k];
     V2 xa[E], ba[BEAM ? E : 1];
     {
-        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int bl = vb / tiles_per_band, i0 = P::tile_row(vb - bl * tiles_per_band, tiles_per_band);
         const int g = threadIdx.x / TPB, t = threadIdx.x % TPB;
         const size_t off = (size_t)bl * d.xband + (size_t)(i0 + g) * d.xpitch;
         const V2* xr = reinterpret_cast<const V2*>(x + off) + t;
@@ -1399,7 +1431,7 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     for (int sit = 0;; ++sit) {
         STAMP(0, sit, 0);
         const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
-        const int bl = vb / tiles_per_band, i0 = (vb - bl * tiles_per_band) * G;
+        const int bl = vb / tiles_per_band, i0 = P::tile_row(vb - bl * tiles_per_band, tiles_per_band);
         cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
         cplx<T> vv[E];
         // ---- even bins: z[n] = x[2n] + i x[2n+1]
@@ -1454,10 +1486,10 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                vv[j] = cplx<T>(xa[j].x, xa[j].y) * ltm[t + TPB * j];
+                vv[j] = cplx<T>(xa[j].x, xa[j].y) * P::tw_row(ltm, t, j);
                 if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
-            const int bln = vbn / tiles_per_band, i0n = (vbn - bln * tiles_per_band) * G;
+            const int bln = vbn / tiles_per_band, i0n = P::tile_row(vbn - bln * tiles_per_band, tiles_per_band);
             const size_t offn = (size_t)bln * d.xband + (size_t)(i0n + g) * d.xpitch;
             const V2* xr = reinterpret_cast<const V2*>(x + offn) + t;
             const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + offn) + t : nullptr;
@@ -1686,9 +1718,22 @@ struct InvP {
     static constexpr int NITE = (NBE + BSTEP - 1) / BSTEP;
     static constexpr int NITO = (NBO + BSTEP - 1) / BSTEP;
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
-    static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + L + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
-    static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE &&
+    // 4096-point fp32 rows (8192-pixel lines), 16 elements per thread, 4 rows: the exchange buffers of four rows leave no
+    // room for the full table w_M^n (32 KB) nor for the parked even-bin result.  SMT: only w_M^t, t < TPB, is kept and
+    // w_M^(t + TPB j) = w_M^t root32(j) (M = 2 L = 32 TPB).  OPF = false: the epilogue operands (x, dot_with2, beam) are
+    // NOT prefetched into registers (vv + ev + the strided pieces already take 100 of the 128) but read where they are
+    // used; what the persistent kernel still buys over the plain one are the tables loaded once and the strided pieces of
+    // the next phase / next tile in flight during every transform.
+    static constexpr bool SMT = sizeof(T) == 4 && E >= 16 && L >= 4096;
+    static constexpr bool OPF = E < 16;
+    static constexpr int NTM = SMT ? F::TPB : L;
+    static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
+    static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
                                (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && (G == 2 || G == 4) && L >= 1024));
+    __device__ __forceinline__ static cplx<T> tw_row(const cplx<T>* ltm, int t, int j) {     // w_M^(t + TPB j)
+        if constexpr (SMT) return j == 0 ? ltm[t] : ltm[t] * root32<T>(j);
+        else return ltm[t + F::TPB * j];
+    }
 };
 
 #ifndef PFB_INV_LIN
@@ -1790,13 +1835,12 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
     if constexpr (inv_lin_ok<T, L, E>()) {
         const cplx<T>* pa = lds + F::pad(t);                                  // Y[t + TPB j]      = pa[cpad(TPB j)]
         const cplx<T>* pb = lds + F::pad(L - PAR - t - F::TPB * (E - 1));     // partner of step j = pb[cpad(TPB (E-1-j))]
-        const cplx<T>* lw = ltm + t;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             cplx<T> yv = pa[F::cpad(F::TPB * j)];
             cplx<T> ym = pb[F::cpad(F::TPB * (E - 1 - j))];
             if (!PAR && j == 0) { if (t == 0) { yv.y = 0; ym.y = 0; } }
-            cplx<T> w = lw[F::TPB * j];
+            cplx<T> w = InvP<T, L, E>::tw_row(ltm, t, j);
             if (PAR) w = w * wq1;
             vv[j] = addrot<true>(addc(yv, ym), mulc(subc(yv, ym), w));
             if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -1838,12 +1882,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     double* red = reinterpret_cast<double*>(smem);
     cplx<T>* ltw = reinterpret_cast<cplx<T>*>(smem + 384);
     cplx<T>* ltm = ltw + P::PTWP;
-    cplx<T>* lds0 = ltm + L;
+    cplx<T>* lds0 = ltm + P::NTM;
     cplx<T>* park = lds0 + (size_t)G * P::STRIDE;
     int vb = blockIdx.x;
     if (vb >= ntiles) return;
     for (int k = threadIdx.x; k < F::PTWC; k += NT) ltw[k] = ptw[k];
-    for (int k = threadIdx.x; k < L; k += NT) ltm[k] = twM[k];
+    for (int k = threadIdx.x; k < P::NTM; k += NT) ltm[k] = twM[k];
     constexpr int SH = 128 / (G * (int)sizeof(cplx<T>) * P::NVB) > 1 ? 128 / (G * (int)sizeof(cplx<T>) * P::NVB) : 1;
     const bool pairing = SH > 1 && (tiles_per_band % (8 * SH)) == 0;
     auto tile = [&](int v, int& bl, int& i0) {
@@ -1858,7 +1902,10 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     int bl, i0;
     tile(vb, bl, i0);
     Blk<T, P::NVB> y[P::NITE];
-    inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
+    // OPF kernels keep the NEXT tile's even-bin pieces in flight across the epilogue; without the registers for that
+    // (!OPF: 16 elements per thread) a tile's even-bin pieces are requested at the top of its own trip instead
+    if constexpr (P::OPF)
+        inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
     // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
     // tile's even-bin transform instead of in one burst behind the epilogue
@@ -1871,8 +1918,13 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
+        if constexpr (!P::OPF) {
+            const int tid = launder((int)threadIdx.x);
+            inv_issue<T, L, E, 0>(Tb, d.nx, i0, tid % G, tid / G, y);
+        }
         cplx<T> vv[E], ev[P::PARK ? 1 : E];
-        V2 xq[E], rq[MODE == 2 ? E : 1], bq[BEAM ? E : 1];
+        constexpr bool OPF = P::OPF;             // epilogue operands prefetched into registers
+        V2 xq[OPF ? E : 1], rq[(OPF && MODE == 2) ? E : 1], bq[(OPF && BEAM) ? E : 1];
         // ---- even bins
         {
             const int tid = launder((int)threadIdx.x);
@@ -1901,7 +1953,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     }
                     if constexpr (K < NPA) {            // first passes: the odd-bin pieces (needed first)
                         inv_issue_slice<T, L, E, 1, (K * P::NITO) / NPA, ((K + 1) * P::NITO) / NPA>(Tb, d.nx, i0, rr, bi, y);
-                    } else {                            // then this tile's x (and beam) rows for the epilogue
+                    } else if constexpr (OPF) {         // then this tile's x (and beam) rows for the epilogue
                         constexpr int KK = K - NPA;
 #pragma unroll
                         for (int j = (KK * E) / NPB; j < ((KK + 1) * E) / NPB; ++j) {
@@ -1932,18 +1984,20 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const V2* dr2 = reinterpret_cast<const V2*>(dot_with2 + rowoff) + t;
             const cplx<T>* Tbn = Tw + (size_t)(band0 + bln) * d.T_band;
             if constexpr (!SPR) {
-                const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+                if constexpr (OPF) {
+                    const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    xq[j] = xr[TPB * j];
-                    if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
-                }
-                if constexpr (BEAM) {
-                    const V2* br = reinterpret_cast<const V2*>(beam + rowoff) + t;
+                    for (int j = 0; j < E; ++j) {
+                        xq[j] = xr[TPB * j];
+                        if constexpr (MODE == 2) rq[j] = dr2[TPB * j];
+                    }
+                    if constexpr (BEAM) {
+                        const V2* br = reinterpret_cast<const V2*>(beam + rowoff) + t;
 #pragma unroll
-                    for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
+                        for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
+                    }
                 }
-                inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
+                if constexpr (OPF) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
             }
             __syncthreads();
             STAMP(2, sit, 8);
@@ -1952,7 +2006,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             if constexpr (SPR) {
                 F::template run<true>(vv, lds, t, ltw, [&](auto k) {
                     constexpr int K = decltype(k)::value;
-                    if constexpr (MODE == 2) {
+                    if constexpr (MODE == 2 && OPF) {
                         if constexpr (K < NPA) {        // dot_with2 rows first: the epilogue waits for them
 #pragma unroll
                             for (int j = (K * E) / NPA; j < ((K + 1) * E) / NPA; ++j) rq[j] = dr2[TPB * j];
@@ -1960,7 +2014,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                             constexpr int KK = K - NPA;
                             inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
                         }
-                    } else {
+                    } else if constexpr (OPF) {
                         inv_issue_slice<T, L, E, 0, (K * P::NITE) / NP, ((K + 1) * P::NITE) / NP>(Tbn, d.nx, i0n, rr, bi, y);
                     }
                 });
@@ -1975,26 +2029,36 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const int g = tid / TPB, t = tid % TPB;
             const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
             V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
+            [[maybe_unused]] const V2* xr_e = reinterpret_cast<const V2*>(x + rowoff) + t;
+            [[maybe_unused]] const V2* br_e = BEAM ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
+            [[maybe_unused]] const V2* dr_e = MODE == 2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) + t : nullptr;
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 cplx<T> e0;
                 if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
-                const cplx<T> zz = e0 + mulc(vv[j], ltm[t + TPB * j]);
+                const cplx<T> zz = e0 + mulc(vv[j], P::tw_row(ltm, t, j));
                 V2 val;
-                const V2 xx = xq[j];
+                V2 xx;
+                [[maybe_unused]] V2 bb;
+                if constexpr (OPF) { xx = xq[j]; if constexpr (BEAM) bb = bq[j]; }
+                else { xx = xr_e[TPB * j]; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 if constexpr (BEAM) {
-                    val.x = zz.x * scale * bq[j].x + sigmainv * xx.x;
-                    val.y = zz.y * scale * bq[j].y + sigmainv * xx.y;
+                    val.x = zz.x * scale * bb.x + sigmainv * xx.x;
+                    val.y = zz.y * scale * bb.y + sigmainv * xx.y;
                 } else {
                     val.x = zz.x * scale + sigmainv * xx.x;
                     val.y = zz.y * scale + sigmainv * xx.y;
                 }
                 if constexpr (SPR && P::PARK) { if (dst) ov[j] = val; else orow[TPB * j] = val; }
                 else orow[TPB * j] = val;
+                // operands read in place (!OPF): a few samples at a time, or every x / dot_with2 load of the tile is
+                // hoisted to the top of the loop and spills
+                if constexpr (!OPF) { if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
-                        const V2 d2 = rq[j];
+                        V2 d2;
+                        if constexpr (OPF) d2 = rq[j]; else d2 = dr_e[TPB * j];
                         acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
                     }
                     acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
@@ -2539,7 +2603,11 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     if constexpr (InvP<T, L, E>::OK) {
         // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
         const bool plain_dots = !dot_with || (dot_with == x);
-        if (ft->inv_persistent && plain_dots && !(dot_with2 && !dot_with)) {
+        // (4096-point rows at 16 elements per thread, operands read in place: the beam-and-two-dots epilogue of the PCG
+        // call needs 5 registers more than the 128 a 1024-thread workgroup gets -- 152 B of scratch inside a kernel whose
+        // point is loads in flight; that one combination stays on the plain kernel)
+        const bool regs_ok = InvP<T, L, E>::OPF || !(beam && dot_with2);
+        if (ft->inv_persistent && plain_dots && regs_ok && !(dot_with2 && !dot_with)) {
             using IP = InvP<T, L, E>;
             const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;

@@ -61,6 +61,36 @@ def test_pcg_allreduce_hook_with_rccl_world1():
         assert res.exchange == 'rccl-native'
         x1, _, res1 = pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True,
                                 backtrack='exact')
+        # (1b) the band-sharded dual update over the same group: chunked, pipelined reduce-scatter + all-gather on RCCL
+        # (dist.exchange_plane_pipelined) -- one rank: bitwise the unsharded kernel's result, odd tail chunk included
+        from pfb_clean_amd.prox.prox_21m import dual_update_numba
+        os.environ['PFB_PD_CHUNK_MB'] = '0.05'
+        try:
+            gq = torch.Generator(device='cuda').manual_seed(5)
+            shp = (3, 4, 67, 133)
+            vp_ = torch.randn(shp, generator=gq, device='cuda', dtype=torch.float64)
+            v_ = torch.randn(shp, generator=gq, device='cuda', dtype=torch.float64)
+            w_ = torch.rand(shp[1:], generator=gq, device='cuda', dtype=torch.float64)
+            assert len(pdist.plane_chunks(v_[0].numel(), 8, 1)) > 2
+            va, vb = v_.clone(), v_.clone()
+            oa, ob = torch.empty_like(v_), torch.empty_like(v_)
+            dual_update_numba(vp_, va, 0.3, sigma=1.7, weight=w_, vp_out=oa)
+            dual_update_numba(vp_, vb, 0.3, sigma=1.7, weight=w_, vp_out=ob, group=True)
+            assert torch.equal(va, vb) and torch.equal(oa, ob)
+        finally:
+            del os.environ['PFB_PD_CHUNK_MB']
+        # (1c) failure protocol of the native exchange (include/pfb_hip.h): healthy -> probe OK; aborted -> the probe,
+        # the exchange and a distributed solve all answer PFB_ERR_COMM instead of enqueueing on a dead communicator
+        from pfb_clean_amd import _lib
+        lib = _lib.load()
+        comm.check()
+        assert lib.pfb_comm_allreduce(comm.handle, None, 0, None) == 0
+        comm.abort()
+        assert lib.pfb_comm_check(comm.handle) == _lib.PFB_ERR_COMM
+        assert lib.pfb_comm_allreduce(comm.handle, None, 0, None) == _lib.PFB_ERR_COMM
+        assert lib.pfb_comm_allreduce(comm.handle, t.data_ptr(), 7, None) == _lib.PFB_ERR_COMM
+        with pytest.raises(_lib.PfbCommError):
+            pcg_fused(A, bt, None, mdiv=1e-2, tol=0.0, maxit=8, minit=8, distributed=True)
         # (2) the fallback: ctypes callback -> torch.distributed.all_reduce
         pdist.close_native_comms()
         os.environ['PFB_NATIVE_COMM'] = '0'
