@@ -532,7 +532,9 @@ def cpu_baseline(plan, psfhat_dev, b_dev, sigmainv, n, nband, args):
         cpu = {"value": round(rate, 4), "unit": "cube-matvecs/s", "cores": threads * nband, "kind": "port",
                "sample": f"oracle pcg (numpy + scipy.fft {scipy.__version__}) on all {nband} bands concurrently, "
                          f"{nband} processes x {threads} FFT workers, {iters} iterations = {iters + 1} cube-matvecs "
-                         f"in {wall:.1f} s; host has {os.cpu_count()} logical cores, {avail} usable by this process",
+                         f"in {wall:.1f} s; host has {os.cpu_count()} logical cores, {avail} usable by this process; "
+                         "core-count sweep on the 256-core MI355X host (tools/cpu_workers_sweep.py, round 2): 16 cores 1.90, "
+                         "64 cores 2.28, 256 cores 0.90 cube-matvecs/s -- 64 is the fastest setting and the default",
                "band_matvecs_per_s": round(rate * nband, 3)}
         return cpu, parity
     finally:
