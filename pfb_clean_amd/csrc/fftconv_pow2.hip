@@ -92,7 +92,8 @@ template <> struct FastCfg<double> { static constexpr int ECOL = 8; static const
 // -> occupancy beats piece size for the latency-bound inverse kernel; the forward kernel
 // keeps 8 rows per workgroup (its strided side is the WRITE, full 128-byte lines).
 template <typename T, int L, int E, int GMAX> constexpr int row_groups();
-#ifndef PFB_ROW_E64_INV          // experiment knobs: elements per thread of the fp64 row kernels at L >= 4096
+#ifndef PFB_ROW_E64_INV          // experiment knobs: elements per thread of the PLAIN fp64 row kernels at L >= 4096 (the persistent
+                                 // inverse kernel has its own: InvPE)
 #define PFB_ROW_E64_INV 8
 #endif
 #ifndef PFB_ROW_E64_FWD
@@ -1082,7 +1083,8 @@ struct FwdP {
     static constexpr int EOK = (E == 8 || E == 16) ? E : 8;
     using F = RegFft<T, L, EOK, false, 0, true, true>;
     static constexpr int TPR = L / EOK;               // threads per row
-    static constexpr int NT = 1024;
+    // fp64 rows of 4096 points: two rows fill the LDS -> 512-thread workgroups (256 registers per thread)
+    static constexpr int NT = (BIG && sizeof(T) == 8) ? 512 : 1024;
     static constexpr int G = NT / TPR;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
@@ -1101,8 +1103,16 @@ struct FwdP {
                              // 0.0633 (sequential parities) / 0.0677 ms against 0.0561 ms for the plain kernel at 2048^2 x 4
 #define PFB_FWDP_E8 0
 #endif
+    // sweep step K advances the bin index by MS = NVB BSTEP: w_M^(MS K) = root32(KR K)
+    static constexpr int KR = (32 * NVB * BSTEP) / (2 * L);
+    // fp64 rows of 4096 points as 2-row 512-thread persistent tiles: 1.87 against 1.21 ms per 2 x 8192^2 for the plain
+    // kernel (profiles/r03_i_*; the same verdict as at 2048 points in round 1) -- PFB_FWDP_F64BIG=1 builds them anyway
+#ifndef PFB_FWDP_F64BIG
+#define PFB_FWDP_F64BIG 0
+#endif
     static constexpr bool OK = (E == 16 || (PFB_FWDP_E8 && E == 8 && sizeof(T) == 4)) && LDS <= (size_t)160 * 1024 &&
-                               (!SMT || (EOK == 16 && 32 * TPR == 2 * L && 16 * NVB * BSTEP == 2 * L));
+                               (PFB_FWDP_F64BIG || !(BIG && sizeof(T) == 8)) &&
+                               (!SMT || (EOK == 16 && 32 * TPR == 2 * L && KR * 2 * L == 32 * NVB * BSTEP && NTM >= TPR));
     // w_M^(t + TPR j) from the table in the LDS
     __device__ __forceinline__ static cplx<T> tw_row(const cplx<T>* ltm, int t, int j) {
         if constexpr (SMT) return j == 0 ? ltm[t] : ltm[t] * root32<T>(j);
@@ -1202,7 +1212,7 @@ __device__ __forceinline__ void post_steps_lin(const cplx<T>* const (&za)[FastCf
 #pragma unroll
         for (int h = 0; h < NVB; ++h) {
             cplx<T> w;
-            if constexpr (P::SMT) w = K == 0 ? lw[h] : lw[h] * root32<T>(2 * K);      // w_M^(m0 + h + MS K), MS = M / 16
+            if constexpr (P::SMT) w = K == 0 ? lw[h] : lw[h] * root32<T>(P::KR * K);  // w_M^(m0 + h + MS K), MS = KR M / 32
             else w = lw[MS * K + h];
             if (PAR) w = w * wq1;
             const cplx<T> zv = za[h][F::cpad(MS * K)];
@@ -1259,7 +1269,7 @@ __device__ __forceinline__ void fwdp_post_lin(const cplx<T>* zr, const cplx<T>* 
 // SPR: the next tile's rows are requested two at a time inside the even-bin sweep (its beam rows inside the odd-bin
 // sweep) instead of in one burst before it: the burst parks all 16 waves at issue (profiles/r02_a_phase_stamps_*).
 template <typename T, int L, bool BEAM, bool SPR = false>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__((FwdP<T, L>::NT))
 k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
                 cplx<T> wq1) {
@@ -1396,7 +1406,7 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
 // JUST LEFT (no extra registers): the even-bin sweep's stores drain and the next rows arrive while the second
 // transform computes, the odd-bin sweep's stores drain during the next tile's first transform.
 template <typename T, int L, bool BEAM>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__((FwdP<T, L>::NT))
 k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptwc, FastDims d, int band0, int tiles_per_band, int ntiles,
                 cplx<T> wq1) {
@@ -1724,8 +1734,14 @@ struct InvP {
     // NOT prefetched into registers (vv + ev + the strided pieces already take 100 of the 128) but read where they are
     // used; what the persistent kernel still buys over the plain one are the tables loaded once and the strided pieces of
     // the next phase / next tile in flight during every transform.
-    static constexpr bool SMT = sizeof(T) == 4 && E >= 16 && L >= 4096;
+    static constexpr bool SMT = E >= 16 && L >= 4096;
     static constexpr bool OPF = E < 16;
+    // NXT: the NEXT tile's even-bin pieces are requested during the odd-bin transform and stay in flight across the
+    // epilogue (always with OPF; without it only where registers remain: the 512-thread fp64 tiles have 256)
+#ifndef PFB_INV_NXT64
+#define PFB_INV_NXT64 0          // measured a tie (1.612 / 1.618 ms): the lighter variant
+#endif
+    static constexpr bool NXT = OPF || (PFB_INV_NXT64 && sizeof(T) == 8);
     static constexpr int NTM = SMT ? F::TPB : L;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
@@ -1734,6 +1750,14 @@ struct InvP {
         if constexpr (SMT) return j == 0 ? ltm[t] : ltm[t] * root32<T>(j);
         else return ltm[t + F::TPB * j];
     }
+};
+
+// elements per thread of the PERSISTENT inverse row kernel: RowCfg's, except fp64 rows of 4096 points (C5) -- there the
+// plain kernel is a 2-row, 1024-thread, 8-elements tile under the 128-VGPR cap, the persistent one a 2-row, 512-thread,
+// 16-elements tile (174-199 VGPRs, no scratch; small tables, operands read in place): 2.30 -> 1.61 ms per 2 x 8192^2.
+// (The plain kernel at 16 elements spills 648 B and takes 3.0 ms: the two kernels keep separate pass tables.)
+template <typename T, int L> struct InvPE {
+    static constexpr int E = (sizeof(T) == 8 && L >= 4096) ? 16 : RowCfg<T, L, true>::E;
 };
 
 #ifndef PFB_INV_LIN
@@ -1853,7 +1877,7 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
         cplx<T> yv = lds[F::pad(m)];
         cplx<T> ym = lds[F::pad(PAR ? (L - 1 - m) : (L - m))];
         if (!PAR && m == 0) { yv.y = 0; ym.y = 0; }
-        cplx<T> w = ltm[m];
+        cplx<T> w = InvP<T, L, E>::tw_row(ltm, t, j);          // w_M^m, m = t + TPB j
         if (PAR) w = w * wq1;
         vv[j] = addrot<true>(addc(yv, ym), mulc(subc(yv, ym), w));
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -1904,7 +1928,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     // OPF kernels keep the NEXT tile's even-bin pieces in flight across the epilogue; without the registers for that
     // (!OPF: 16 elements per thread) a tile's even-bin pieces are requested at the top of its own trip instead
-    if constexpr (P::OPF)
+    if constexpr (P::NXT)
         inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
     // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
@@ -1918,7 +1942,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
-        if constexpr (!P::OPF) {
+        if constexpr (!P::NXT) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tb, d.nx, i0, tid % G, tid / G, y);
         }
@@ -1997,7 +2021,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                         for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
                     }
                 }
-                if constexpr (OPF) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
+                if constexpr (P::NXT) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
             }
             __syncthreads();
             STAMP(2, sit, 8);
@@ -2014,7 +2038,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                             constexpr int KK = K - NPA;
                             inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
                         }
-                    } else if constexpr (OPF) {
+                    } else if constexpr (P::NXT) {
                         inv_issue_slice<T, L, E, 0, (K * P::NITE) / NP, ((K + 1) * P::NITE) / NP>(Tbn, d.nx, i0n, rr, bi, y);
                     }
                 });
@@ -2126,6 +2150,7 @@ struct FastTables {            // device tables owned by the plan (stored behind
     void* ptwc_col;            // compact (w only) table of the column transform, copied to LDS
     void* ptw_row;             // forward row kernel (E = 16)
     void* ptw_row_inv;         // inverse row kernel (E = 8): COMPACT table, copied to LDS
+    void* ptw_row_inv_p;       // the persistent inverse kernel's, where its elements per thread differ (InvPE); else == ptw_row_inv
     void* twM;                 // exp(-2 pi i n / M), n < L
     int col_persistent;        // PFB_COL_PERSIST (default: auto by size): persistent prefetching column kernel
     void* ptwc_row_fwd;        // compact pass table of the persistent forward row kernel (its own E)
@@ -2166,7 +2191,7 @@ static int prep_ptw_compact(void** dev) {
 
 template <typename T, int L>
 static int set_invp_attr() {
-    constexpr int E = RowCfg<T, L, true>::E;
+    constexpr int E = InvPE<T, L>::E;
     if constexpr (InvP<T, L, E>::OK) {
 #define PFB_INVATTR(MODE, BM)                                                                           \
         PFB_HIP_CHECK(hipFuncSetAttribute((const void*)(k_row_inv_pow2p<T, L, E, MODE, BM, false>),      \
@@ -2221,6 +2246,8 @@ static int prep_tables(pfb_conv_plan* p, FastTables* ft) {
     switch (L) {
 #define X(NN) case NN: rc = prep_ptw<T, NN, RowCfg<T, NN, false>::E>(&ft->ptw_row);                   \
         if (rc == PFB_OK) rc = prep_ptw_compact<T, NN, RowCfg<T, NN, true>::E>(&ft->ptw_row_inv);    \
+        if (rc == PFB_OK) { if (InvPE<T, NN>::E != RowCfg<T, NN, true>::E) rc = prep_ptw_compact<T, NN, InvPE<T, NN>::E>(&ft->ptw_row_inv_p); \
+                            else ft->ptw_row_inv_p = ft->ptw_row_inv; }                            \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_fwd_pow2<T, NN, RowCfg<T, NN, false>::E>, \
             hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));                                   \
         if (rc == PFB_OK) PFB_HIP_CHECK(hipFuncSetAttribute((const void*)k_row_inv_pow2<T, NN, RowCfg<T, NN, true>::E>, \
@@ -2304,6 +2331,7 @@ void pow2_release(pfb_conv_plan* p) {
     if (ft->ptwc_col) (void)hipFree(ft->ptwc_col);
     if (ft->ptwc_col_x) (void)hipFree(ft->ptwc_col_x);
     if (ft->ptw_row) (void)hipFree(ft->ptw_row);
+    if (ft->ptw_row_inv_p && ft->ptw_row_inv_p != ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv_p);
     if (ft->ptw_row_inv) (void)hipFree(ft->ptw_row_inv);
     if (ft->twM) (void)hipFree(ft->twM);
     if (ft->ptwc_row_fwd) (void)hipFree(ft->ptwc_row_fwd);
@@ -2600,15 +2628,16 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     using F = RegFft<T, L, E, RowCfg<T, L, true>::WAVE>;
     constexpr int G = row_groups<T, L, E, RowCfg<T, L, true>::GMAX>();
     FastDims d{p->nx, p->ny, p->M, p->T_elems_per_band, p->psf_elems_per_band, (size_t)p->ny, (size_t)p->nx * p->ny};
-    if constexpr (InvP<T, L, E>::OK) {
+    constexpr int EP = InvPE<T, L>::E;
+    if constexpr (InvP<T, L, EP>::OK) {
         // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
         const bool plain_dots = !dot_with || (dot_with == x);
         // (4096-point rows at 16 elements per thread, operands read in place: the beam-and-two-dots epilogue of the PCG
         // call needs 5 registers more than the 128 a 1024-thread workgroup gets -- 152 B of scratch inside a kernel whose
         // point is loads in flight; that one combination stays on the plain kernel)
-        const bool regs_ok = InvP<T, L, E>::OPF || !(beam && dot_with2);
+        const bool regs_ok = InvP<T, L, EP>::OPF || sizeof(T) == 8 || !(beam && dot_with2);  // (512-thread fp64 tiles have 256 registers)
         if (ft->inv_persistent && plain_dots && regs_ok && !(dot_with2 && !dot_with)) {
-            using IP = InvP<T, L, E>;
+            using IP = InvP<T, L, EP>;
             const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
@@ -2616,9 +2645,9 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
             static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
             static const int defer = [] { const char* e = getenv("PFB_INV_DEFER"); return e ? atoi(e) : 1; }();   // A/B
 #define PFB_INVP3(MODE, BM, SP)                                                                         \
-            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, E, MODE, BM, SP>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
+            hipLaunchKernelGGL((k_row_inv_pow2p<T, L, EP, MODE, BM, SP>), dim3(grid), dim3(IP::NT), IP::LDS, st, \
                                (const cplx<T>*)p->T, (const cplx<T>*)ft->twM,                           \
-                               (const cplx<T>*)ft->ptw_row_inv, (const T*)x, (const T*)beam,            \
+                               (const cplx<T>*)ft->ptw_row_inv_p, (const T*)x, (const T*)beam,          \
                                (const T*)dot_with2, (T*)out, p->partials, d, band0, tiles_per_band,     \
                                ntiles, (T)scale, (T)sigmainv, wq1, defer, tail)
 #define PFB_INVP2(MODE, BM) do { if (spread) PFB_INVP3(MODE, BM, true); else PFB_INVP3(MODE, BM, false); } while (0)

@@ -1,4 +1,5 @@
-"""Persistent row kernels for 4096-point rows (ny = 8192, fp32: small twiddle tables, 4-row tiles) against the plain
+"""Persistent row kernels for 4096-point rows (ny = 8192; fp32: 4-row tiles, fp64: 2-row 512-thread tiles; small twiddle
+tables) against the plain
 kernels (PFB_FWD_PERSIST=0 / PFB_INV_PERSIST=0) on the same inputs, every epilogue mode.  The switches are read per
 plan, so one process compares both.
     python tools/check_rows4096.py
@@ -14,8 +15,9 @@ from pfb_clean_amd.operators.psf import PsfConvPlan      # noqa: E402
 lib = _lib.load()
 dev = torch.device('cuda')
 ok = True
-for nx, ny, nb in ((256, 8192, 2), (1024, 8192, 1), (8192, 8192, 1)):
-    dt, cdt = torch.float32, torch.complex64
+for nx, ny, nb, dt in ((256, 8192, 2, torch.float32), (1024, 8192, 1, torch.float32), (8192, 8192, 1, torch.float32),
+                       (256, 8192, 2, torch.float64), (2048, 8192, 1, torch.float64)):
+    cdt = torch.complex64 if dt == torch.float32 else torch.complex128
     g = torch.Generator(device=dev).manual_seed(nx + ny)
     psfhat = ((torch.rand((nb, 2 * nx, ny + 1), generator=g, device=dev, dtype=dt) - 0.3)
               + 1j * (torch.rand((nb, 2 * nx, ny + 1), generator=g, device=dev, dtype=dt) - 0.5)).to(cdt) / (nx * ny) ** 0.5
@@ -46,9 +48,9 @@ for nx, ny, nb in ((256, 8192, 2), (1024, 8192, 1), (8192, 8192, 1)):
         e = (o0 - o1).abs().max().item() / o0.abs().max().item()
         ed = ((d0 - d1).abs() / (d0.abs() + 1e-30)).max().item()
         worst = max(worst, e, ed if ed < 1 else 0.0 if d0.abs().max().item() == 0 else ed)
-    good = worst < 2e-6
+    good = worst < (2e-6 if dt == torch.float32 else 1e-13)
     ok &= good
-    print(f"{nx} x {ny} x {nb} fp32: max rel difference over 6 modes (conv, fused dots) {worst:.2e} {'OK' if good else 'FAIL'}",
+    print(f"{nx} x {ny} x {nb} {str(dt)[6:]}: max rel difference over 6 modes (conv, fused dots) {worst:.2e} {'OK' if good else 'FAIL'}",
           flush=True)
 os.environ.pop('PFB_FWD_PERSIST', None)
 os.environ.pop('PFB_INV_PERSIST', None)
