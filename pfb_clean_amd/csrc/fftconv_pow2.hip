@@ -1734,7 +1734,7 @@ struct InvP {
     // NOT prefetched into registers (vv + ev + the strided pieces already take 100 of the 128) but read where they are
     // used; what the persistent kernel still buys over the plain one are the tables loaded once and the strided pieces of
     // the next phase / next tile in flight during every transform.
-    static constexpr bool SMT = E >= 16 && L >= 4096;
+    static constexpr bool SMT = E >= 16 && (L >= 4096 || sizeof(T) == 8);
     static constexpr bool OPF = E < 16;
     // NXT: the NEXT tile's even-bin pieces are requested during the odd-bin transform and stay in flight across the
     // epilogue (always with OPF; without it only where registers remain: the 512-thread fp64 tiles have 256)
@@ -1756,8 +1756,11 @@ struct InvP {
 // plain kernel is a 2-row, 1024-thread, 8-elements tile under the 128-VGPR cap, the persistent one a 2-row, 512-thread,
 // 16-elements tile (174-199 VGPRs, no scratch; small tables, operands read in place): 2.30 -> 1.61 ms per 2 x 8192^2.
 // (The plain kernel at 16 elements spills 648 B and takes 3.0 ms: the two kernels keep separate pass tables.)
+#ifndef PFB_INVPE64_MINL       // smallest fp64 row length that takes the 16-element persistent tile
+#define PFB_INVPE64_MINL 4096
+#endif
 template <typename T, int L> struct InvPE {
-    static constexpr int E = (sizeof(T) == 8 && L >= 4096) ? 16 : RowCfg<T, L, true>::E;
+    static constexpr int E = (sizeof(T) == 8 && L >= PFB_INVPE64_MINL) ? 16 : RowCfg<T, L, true>::E;
 };
 
 #ifndef PFB_INV_LIN

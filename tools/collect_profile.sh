@@ -17,9 +17,9 @@ run() {   # name, seconds, command...
     echo "[$(date +%H:%M:%S)] rc=$rc $name" | tee -a "$OUT/steps.log"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit 99; fi
 }
-run stats 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/stats" -- python3 "$ROOT/bench.py" --no-cpu --steps 20 --warmup 5 --repeats 2 "$@"
-run fetch 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$W/fetch" -- python3 "$ROOT/bench.py" --no-cpu --steps 4 --warmup 1 --repeats 1 "$@"
-run write 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$W/write" -- python3 "$ROOT/bench.py" --no-cpu --steps 4 --warmup 1 --repeats 1 "$@"
+run stats 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$W/stats" -- python3 "$ROOT/bench.py" --no-cpu --configs none --steps 20 --warmup 5 --repeats 2 "$@"
+run fetch 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$W/fetch" -- python3 "$ROOT/bench.py" --no-cpu --configs none --steps 4 --warmup 1 --repeats 1 "$@"
+run write 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$W/write" -- python3 "$ROOT/bench.py" --no-cpu --configs none --steps 4 --warmup 1 --repeats 1 "$@"
 find "$W/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/stats/bench_kernel_stats.csv" \;
 for p in fetch write; do
     f=$(find "$W/$p" -name '*counter_collection.csv' | head -1)

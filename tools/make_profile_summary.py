@@ -27,7 +27,7 @@ bench = open(bench_json).read().strip().splitlines()[-1]
 bj = json.loads(bench)
 with open(os.path.join(root, 'profiles', tag + '_bench.json'), 'w') as f:
     f.write(bench + '\n')
-lines = [f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu`", "", note, "",
+lines = [f"# {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu --configs none ...` ({bj['config']['workload']})", "", note, "",
          f"bench line of the un-profiled default run (`profiles/{tag}_bench.json`): {bj['value']:.1f} {bj['unit']}, "
          f"{bj['ms_per_step']:.3f} ms/step, roofline.frac {bj['roofline']['frac']:.3f}.", "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
@@ -70,7 +70,10 @@ import subprocess
 sys.path.insert(0, root)
 import bench as _bench
 cfg = bj.get('config', {})
-size = int(os.environ.get('PFB_PROF_SIZE', 4096))
+try:
+    size = int(str(cfg.get('workload', '4096x')).split('x')[0])
+except ValueError:
+    size = int(os.environ.get('PFB_PROF_SIZE', 4096))
 out['config'] = dict(workload='pcg', size=size, bands=int(cfg.get('bands_per_gpu', 8)), dtype=bj.get('dtype', 'f32'))
 try:
     out['commit'] = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
