@@ -653,7 +653,10 @@ struct ColX {
     static_assert(E == 8, "root32: the twiddle constants are the 4E-th roots of unity");
 };
 
-template <typename T, int H, int E, bool NT = false>
+#ifndef PFB_COLX_QLATE
+#define PFB_COLX_QLATE 1
+#endif
+template <typename T, int H, int E, bool NT = false, bool QLATE = (PFB_COLX_QLATE != 0)>
 __global__ void __launch_bounds__((ColX<T, H, E>::NT), 2)
 k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             const cplx<T>* __restrict__ twP, const cplx<T>* __restrict__ ptwc,
@@ -694,8 +697,10 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             al[j] = loadb<T, NVB>(c0 + NVB * TPB * j);
             ah[j] = loadb<T, NVB>(c0 + NVB * (HS + TPB * j));
         }
+        if constexpr (!QLATE) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) q[j] = ldq(p0 + NVB * TPB * j);
+            for (int j = 0; j < E; ++j) q[j] = ldq(p0 + NVB * TPB * j);
+        }
     }
     __syncthreads();                                            // tables visible
 #pragma unroll 1
@@ -718,13 +723,28 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
                 for (int c = 0; c < NVB; ++c) vv[c][j] = vv[c][j] * q[j].c[c];
             }
         };
-        auto ifft_q = [&](const cplx<T>* pq) __attribute__((always_inline)) {   // inverse transform; its passes request the slice at pq
-            F::template runN<true, NVB>(vv, lds, t, ltw, [&](auto k) {
-                constexpr int K = decltype(k)::value;
+        // PSF slices: QLATE requests the slice of round r inside the FORWARD transform of round r (one transform of
+        // lead) instead of inside the inverse transform of the round before (two): q is then dead across every
+        // accumulate / combine step, which is where the registers run out (fp64: 140 B of scratch per lane = 2.35 GB of
+        // spill traffic per 2-band launch, a quarter of the kernel's HBM bytes -- profiles/r03_m_c5_hbm_traffic.json)
+        auto qslice = [&](auto k, const cplx<T>* pq) __attribute__((always_inline)) {
+            constexpr int K = decltype(k)::value;
 #pragma unroll
-                for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = ldq(pq + NVB * TPB * j);
+            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) q[j] = ldq(pq + NVB * TPB * j);
+        };
+        auto fft_q = [&](const cplx<T>* pq, auto&& extra) __attribute__((always_inline)) {     // forward transform of a round
+            F::template runN<false, NVB>(vv, lds, t, ltw, [&](auto k) {
+                if constexpr (QLATE) qslice(k, pq);
+                extra(k);
             });
         };
+        auto ifft_q = [&](const cplx<T>* pq, auto&& extra) __attribute__((always_inline)) {   // inverse transform (!QLATE: requests the slice at pq)
+            F::template runN<true, NVB>(vv, lds, t, ltw, [&](auto k) {
+                if constexpr (!QLATE) qslice(k, pq);
+                else extra(k);
+            });
+        };
+        auto none = [](auto) {};
         STAMP(1, it, 0);
         // ---- round r = 0:  a_lo + a_hi
 #pragma unroll
@@ -732,10 +752,10 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
 #pragma unroll
             for (int c = 0; c < NVB; ++c) vv[c][j] = al[j].c[c] + ah[j].c[c];
         }
-        F::template runN<false, NVB>(vv, lds, t, ltw);
+        fft_q(ps, none);
         STAMP(1, it, 1);
         mulq();
-        ifft_q(ps + (size_t)2 * HS * NVB);
+        ifft_q(ps + (size_t)2 * HS * NVB, none);
         STAMP(1, it, 2);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
@@ -753,10 +773,10 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
         STAMP(1, it, 3);
-        F::template runN<false, NVB>(vv, lds, t, ltw);
+        fft_q(ps + (size_t)2 * HS * NVB, none);
         STAMP(1, it, 4);
         mulq();
-        ifft_q(ps + (size_t)1 * HS * NVB);
+        ifft_q(ps + (size_t)1 * HS * NVB, none);
         STAMP(1, it, 5);
         {
             const cplx<T> w1 = wt(), wt2 = w1 * w1;
@@ -792,14 +812,24 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             }
         }
         STAMP(1, it, 6);
-        F::template runN<false, NVB>(vv, lds, t, ltw, [&](auto k) {
+        // the next item's column: upper half into a_hi's registers (free since the inputs of rounds 1 and 3 were formed),
+        // lower half into a_lo's (free once round 3's input has moved to vv).  Without QLATE they ride in the forward
+        // transforms of rounds 1 / 3; with it those carry the PSF slices and the column rides in the inverse transforms,
+        // so that no transform has more than five arrays of E blocks live.
+        auto ld_ah = [&](auto k) __attribute__((always_inline)) {
             constexpr int K = decltype(k)::value;
 #pragma unroll
             for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) ah[j] = loadb<T, NVB>(cn + NVB * (HS + TPB * j));
-        });
+        };
+        auto ld_al = [&](auto k) __attribute__((always_inline)) {
+            constexpr int K = decltype(k)::value;
+#pragma unroll
+            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) al[j] = loadb<T, NVB>(cn + NVB * TPB * j);
+        };
+        if constexpr (QLATE) fft_q(ps + (size_t)1 * HS * NVB, none); else fft_q(ps + (size_t)1 * HS * NVB, ld_ah);
         STAMP(1, it, 7);
         mulq();
-        ifft_q(ps + (size_t)3 * HS * NVB);
+        ifft_q(ps + (size_t)3 * HS * NVB, ld_ah);
         STAMP(1, it, 8);
         {
             const cplx<T> w1t = wt();
@@ -824,14 +854,10 @@ k_col_pow2x(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
             for (int c = 0; c < NVB; ++c) vv[c][j] = al[j].c[c];
         }
         STAMP(1, it, 9);
-        F::template runN<false, NVB>(vv, lds, t, ltw, [&](auto k) {
-            constexpr int K = decltype(k)::value;
-#pragma unroll
-            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) al[j] = loadb<T, NVB>(cn + NVB * TPB * j);
-        });
+        if constexpr (QLATE) fft_q(ps + (size_t)3 * HS * NVB, none); else fft_q(ps + (size_t)3 * HS * NVB, ld_al);
         STAMP(1, it, 10);
         mulq();
-        ifft_q(psn);
+        ifft_q(psn, ld_al);
         STAMP(1, it, 11);
         if (active) {
             const cplx<T> w1t = wt(), w3t = w1t * (w1t * w1t);
