@@ -2079,7 +2079,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         // ---- z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
         {
             const int tid = launder((int)threadIdx.x);
-            const int g = tid / TPB, t = tid % TPB;
+            int g = tid / TPB;
+            const int t = tid % TPB;
+            // a row is shared by whole waves (TPB a multiple of 64): its index is wave-uniform -- said explicitly, the
+            // row bases live in SGPRs and the 2-KB steps of the unrolled operand / result streams cost scalar adds instead
+            // of a 64-bit VGPR address per stream and sample
+            if constexpr (TPB % 64 == 0 && !P::OPF) g = __builtin_amdgcn_readfirstlane(g);
             const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
             V2* orow = reinterpret_cast<V2*>(out + rowoff) + t;
             [[maybe_unused]] const V2* xr_e = reinterpret_cast<const V2*>(x + rowoff) + t;
