@@ -1110,15 +1110,20 @@ struct FwdP {
     using F = RegFft<T, L, EOK, false, 0, true, true>;
     static constexpr int TPR = L / EOK;               // threads per row
     // fp64 rows of 4096 points: two rows fill the LDS -> 512-thread workgroups (256 registers per thread)
-    static constexpr int NT = (BIG && sizeof(T) == 8) ? 512 : 1024;
+#ifndef PFB_FWDP_HALF       // experiment: 2048-point fp32 rows as 4-row, 512-thread tiles with small tables (74 KB of LDS): TWO
+#define PFB_FWDP_HALF 0     // independent workgroups per CU, 64-byte pieces XCD-paired to full lines
+#endif
+    static constexpr bool HALF = PFB_FWDP_HALF && sizeof(T) == 4 && L == 2048;
+    static constexpr int NT = ((BIG && sizeof(T) == 8) || HALF) ? 512 : 1024;
     static constexpr int G = NT / TPR;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
     static constexpr int NBE = (L + NVB) / NVB;
     static constexpr int NBO = L / NVB;
     static constexpr int BSTEP = NT / G;
-    static constexpr bool SMT = BIG;
+    static constexpr bool SMT = BIG || HALF;
     static constexpr int NTM = SMT ? NVB * BSTEP : L; // entries of the w_M table kept in the LDS
+    static constexpr int WG_PER_CU = HALF ? 2 : 1;
     static constexpr int PTWP = (F::PTWC + 1) & ~1;
     static constexpr size_t LDS = sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE);
     // (an fp64 version with two-row 512-thread tiles -- what the LDS allows -- writes 32-byte pieces and
@@ -2621,7 +2626,7 @@ static void launch_row_fwd(pfb_conv_plan* p, const FastTables* ft, void* Tbuf, i
         if (ft->fwd_persistent) {
             using FP = FwdP<T, L>;
             const int tiles_per_band = p->nx / FP::G, ntiles = tiles_per_band * nb;
-            const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
+            const int grid = ntiles < ft->num_cu * FP::WG_PER_CU ? ntiles : ft->num_cu * FP::WG_PER_CU;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
             // spreading the next tile's row requests over the even-bin sweep measured SLOWER here (0.389 -> 0.411 ms at
