@@ -1773,6 +1773,13 @@ struct InvP {
 #define PFB_INV_NXT64 0          // measured a tie (1.612 / 1.618 ms): the lighter variant
 #endif
     static constexpr bool NXT = OPF || (PFB_INV_NXT64 && sizeof(T) == 8);
+    // NXE: neither -- but the next tile's even-bin pieces are requested at the START of the epilogue (the transforms are
+    // over, their temporaries gone) instead of at the top of the next trip, where they were waited for right away
+    // (profiles/r03_q_phase_stamps_8192x2_*: 8.4 us of a 45 us trip)
+#ifndef PFB_INV_NXE
+#define PFB_INV_NXE 0           // measured: 1.955 vs 1.639 ms per 2 x 8192^2 fp64 (the pieces queue behind the epilogue's own loads): off
+#endif
+    static constexpr bool NXE = !NXT && PFB_INV_NXE && sizeof(T) == 8;      // (fp32 at 128 registers: 52-132 B of scratch)
     static constexpr int NTM = SMT ? F::TPB : L;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
@@ -1962,7 +1969,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     // OPF kernels keep the NEXT tile's even-bin pieces in flight across the epilogue; without the registers for that
     // (!OPF: 16 elements per thread) a tile's even-bin pieces are requested at the top of its own trip instead
-    if constexpr (P::NXT)
+    if constexpr (P::NXT || P::NXE)
         inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
     // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
@@ -1976,7 +1983,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
-        if constexpr (!P::NXT) {
+        if constexpr (!P::NXT && !P::NXE) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tb, d.nx, i0, tid % G, tid / G, y);
         }
@@ -2081,6 +2088,10 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             }
             STAMP(2, sit, 10);
         }
+        if constexpr (P::NXE) {
+            const int tid = launder((int)threadIdx.x);
+            inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, tid % G, tid / G, y);
+        }
         // ---- z[n] = e[n] + conj(w_M^n) o[n] ;  y[2n] = Re z, y[2n+1] = Im z
         {
             const int tid = launder((int)threadIdx.x);
@@ -2116,7 +2127,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 else orow[TPB * j] = val;
                 // operands read in place (!OPF): a few samples at a time, or every x / dot_with2 load of the tile is
                 // hoisted to the top of the loop and spills
-                if constexpr (!OPF) { if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (!OPF) { if (sizeof(T) == 4 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
