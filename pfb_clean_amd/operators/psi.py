@@ -119,3 +119,36 @@ class Psi(object):
             self.close()
         except Exception:
             pass
+
+
+class psi_band(object):
+    """One band of the dictionary -- the object pfb/operators/psi.py:17-123 `psi_band_maker` returns (a numba jitclass
+    there, psi.py:141-256): `dot(x (nx, ny), alphao (nbasis, Nymax, Nxmax))`, `hdot(alpha, xo (nx, ny))`, both in place,
+    attributes `bases, nbasis, nx, ny, Nx, Ny, Nxmax, Nymax`.  Backed by a one-band Psi plan (same kernels)."""
+
+    def __init__(self, psi):
+        self._psi = psi
+        self.bases, self.nbasis = psi.bases, psi.nbasis
+        self.nx, self.ny = psi.nx, psi.ny
+        self.Nx, self.Ny = psi.nx, psi.ny          # extents of the 'self' block (psi.py:183-184)
+        self.Nxmax, self.Nymax = psi.Nxmax, psi.Nymax
+
+    def dot(self, x, alphao):
+        """signal to coeffs (psi.py:187-218)"""
+        if x.ndim != 2 or alphao.ndim != 3:
+            raise ValueError("psi_band.dot: x is (nx, ny), alphao (nbasis, Nymax, Nxmax)")
+        self._psi.dot(x[None], alphao[None])
+        return alphao
+
+    def hdot(self, alpha, xo):
+        """coeffs to signal (psi.py:220-256)"""
+        if xo.ndim != 2 or alpha.ndim != 3:
+            raise ValueError("psi_band.hdot: alpha is (nbasis, Nymax, Nxmax), xo (nx, ny)")
+        self._psi.hdot(alpha[None], xo[None])
+        return xo
+
+
+def psi_band_maker(nx, ny, bases, nlevel):
+    """pfb/operators/psi.py:17-123: the per-band operator for an (nx, ny) image; ValueError for an impossible
+    decomposition level (:44-46)."""
+    return psi_band(Psi(1, nx, ny, bases, nlevel, 1))

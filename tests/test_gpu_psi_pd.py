@@ -208,6 +208,36 @@ def test_primal_dual_with_a_callers_own_affine_synthesis(amd):
     assert maxerr(xl.cpu().numpy(), xo_) > 1e-6
 
 
+def test_psi_band_maker_single_band_object(amd):
+    """psi_band_maker (psi.py:17-123) / psi_band.dot / hdot (psi.py:187-256): the per-band object of the reference, 2-D
+    image and (nbasis, Nymax, Nxmax) coefficients, in place, numpy and device tensors; equals one band of Psi."""
+    from pfb_clean_amd.operators.psi import psi_band_maker
+    rng = np.random.default_rng(31)
+    nx, ny, bases, nlevel = 128, 64, ['self', 'db1', 'db3'], 2
+    pb = psi_band_maker(nx, ny, bases, nlevel)
+    ref = owv.Psi(1, nx, ny, bases, nlevel, 1)
+    assert (pb.Nxmax, pb.Nymax, pb.nbasis, pb.Nx, pb.Ny) == (ref.Nxmax, ref.Nymax, 3, nx, ny)
+    x = rng.standard_normal((nx, ny))
+    a = np.full((3, pb.Nymax, pb.Nxmax), 2.5)
+    want = np.full((1, 3, pb.Nymax, pb.Nxmax), 2.5)
+    assert pb.dot(x, a) is a
+    ref.dot(x[None], want)
+    assert maxerr(a, want[0]) < 1e-13
+    xo = np.empty((nx, ny))
+    pb.hdot(a * (want[0] != 2.5), xo)
+    back = np.zeros((1, nx, ny))
+    ref.hdot(want * (want != 2.5), back)
+    assert maxerr(xo, back[0]) < 1e-12
+    xt = torch.from_numpy(x).cuda()
+    at = torch.zeros((3, pb.Nymax, pb.Nxmax), dtype=torch.float64, device='cuda')
+    pb.dot(xt, at)
+    assert maxerr(at.cpu().numpy() * (want[0] != 2.5), want[0] * (want[0] != 2.5)) < 1e-13
+    with pytest.raises(ValueError):
+        psi_band_maker(16, 16, ['db5'], 3)
+    with pytest.raises(ValueError):
+        pb.dot(x[None], a)
+
+
 def test_psi_device_tensors_adjoint_and_errors(amd):
     rng = np.random.default_rng(9)
     nband, nx, ny = 2, 96, 80
