@@ -296,6 +296,13 @@ int pfb_dual_apply_chunk(int dtype, const void* vp, void* v, const void* weight,
                          double lam, double sigma, int nband, size_t count, size_t band_stride,
                          void* vp_out, void* stream);
 
+/* The band-l2-NORM variants (pfb/prox/prox_21.py; the "m" functions threshold |sum over bands|, these the Euclidean norm
+ * over bands).  pfb_prox_21: prox_21_numba (prox_21.py:23-48) -- and, with sigma = 1, the array form prox_21 (:5-20);
+ * pfb_dual_update_l2: dual_update_numba of the same file (:62-88), in place on v.  Shapes as for the "m" forms. */
+int pfb_prox_21(int dtype, const void* v, void* result, const void* weight,
+                double lam, double sigma, int nband, size_t nper, void* stream);
+int pfb_dual_update_l2(int dtype, const void* vp, void* v, const void* weight,
+                       double lam, double sigma, int nband, size_t nper, void* stream);
 /* pfb/prox/prox_21m.py:31-61 prox_21m_numba */
 int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight,
                  double lam, double sigma, int nband, size_t nper, void* stream);

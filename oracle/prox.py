@@ -7,6 +7,8 @@ Test infrastructure (see oracle/__init__.py).  Follows
   pfb/prox/prox_21m.py:64-71   dual_update    (numpy form)
   pfb/prox/prox_21m.py:76-103  dual_update_numba (in place on v)
   pfb/prox/prox_21.py:5-20     prox_21        (band-l2-NORM variant)
+  pfb/prox/prox_21.py:23-48    prox_21_numba  (band-l2-NORM variant, writes `result`)
+  pfb/prox/prox_21.py:62-88    dual_update_numba of that file (here: dual_update_numba_l2)
 
 The numba loops are vectorised over (basis, y, x); the band axis is axis 0.
 """
@@ -61,6 +63,30 @@ def dual_update_numba(vp, v, lam, sigma=1.0, weight=None):
        where a != 0: v *= 1 - max(a - lam*w/sigma, 0)/a."""
     vt = vp + sigma * v
     a = np.abs(np.sum(vt, axis=0) / sigma)
+    soft = np.maximum(a - lam * weight / sigma, 0.0)
+    nz = a != 0
+    fac = np.ones_like(a)
+    fac[nz] = 1.0 - soft[nz] / a[nz]
+    v[...] = vt * fac[None]
+
+
+def prox_21_numba(v, result, lam, sigma=1.0, weight=None):
+    """prox_21.py:23-48: a = ||v[:, b, i]||_2 / sigma; result = 0 where a == 0 else
+    v * max(a - lam*w/sigma, 0) / a / sigma."""
+    a = np.linalg.norm(v, axis=0) / sigma
+    soft = np.maximum(a - lam * weight / sigma, 0.0)
+    nz = a != 0
+    fac = np.zeros_like(a)
+    fac[nz] = soft[nz] / a[nz] / sigma
+    result[...] = v * fac[None]
+    result[:, ~nz] = 0.0
+
+
+def dual_update_numba_l2(vp, v, lam, sigma=1.0, weight=None):
+    """prox_21.py:62-88, in place on v: vt = vp + sigma*v ; a = ||vt||_2 / sigma ; v = vt ;
+       where a != 0: v *= 1 - max(a - lam*w/sigma, 0)/a."""
+    vt = vp + sigma * v
+    a = np.linalg.norm(vt, axis=0) / sigma
     soft = np.maximum(a - lam * weight / sigma, 0.0)
     nz = a != 0
     fac = np.ones_like(a)

@@ -83,6 +83,8 @@ SIGNATURES = {
     'pfb_dual_update': (_i, [_i, _vp, _vp, _vp, _d, _d, _i, _sz, _vp, _vp]),
     'pfb_dual_bandsum': (_i, [_i, _vp, _vp, _d, _i, _sz, _vp, _vp]),
     'pfb_dual_apply': (_i, [_i, _vp, _vp, _vp, _vp, _d, _d, _i, _sz, _vp, _vp]),
+    'pfb_prox_21': (_i, [_i, _vp, _vp, _vp, _d, _d, _i, _sz, _vp]),
+    'pfb_dual_update_l2': (_i, [_i, _vp, _vp, _vp, _d, _d, _i, _sz, _vp]),
     'pfb_dual_bandsum_chunk': (_i, [_i, _vp, _vp, _d, _i, _sz, _sz, _vp, _vp]),
     'pfb_dual_apply_chunk': (_i, [_i, _vp, _vp, _vp, _vp, _d, _d, _i, _sz, _sz, _vp, _vp]),
     'pfb_clark_subminor': (_i, [_i, _vp, _sz, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _d, _d, _i, _vp, _vp]),

@@ -1032,6 +1032,50 @@ k_prox_21m(const T* __restrict__ v, T* __restrict__ res, const T* __restrict__ w
     }
 }
 
+// ---- the band-l2-NORM variants of pfb/prox/prox_21.py (the "m" kernels above threshold |sum over bands|, these the
+// Euclidean norm over bands).  Off the hot path (the live workers use the "m" forms): plain grid-stride kernels, the
+// norm accumulated in fp64.
+// prox_21_numba (prox_21.py:23-48): a = ||v[:, i]|| / sigma; result = 0 where a == 0, else v max(a - lam w / sigma, 0) / a / sigma
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_prox_21_l2(const T* __restrict__ v, T* __restrict__ res, const T* __restrict__ w, T lam, T sigma, int nband, size_t nper) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper; i += (size_t)gridDim.x * blockDim.x) {
+        double ss = 0.0;
+        for (int b = 0; b < nband; ++b) { const double t = (double)v[(size_t)b * nper + i]; ss += t * t; }
+        const T a = (T)sqrt(ss) / sigma;
+        if (a == T(0)) {
+            for (int b = 0; b < nband; ++b) res[(size_t)b * nper + i] = T(0);
+            continue;
+        }
+        const T soft = fmax(a - lam * w[i] / sigma, T(0));
+        for (int b = 0; b < nband; ++b) res[(size_t)b * nper + i] = v[(size_t)b * nper + i] * soft / a / sigma;
+    }
+}
+// dual_update_numba of prox_21.py:62-88, in place on v: vt = vp + sigma v; a = ||vt[:, i]|| / sigma; v = vt, and where
+// a != 0: v *= 1 - max(a - lam w / sigma, 0) / a
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_dual_update_l2(const T* __restrict__ vp, T* __restrict__ v, const T* __restrict__ w, T lam, T sigma, int nband, size_t nper) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nper; i += (size_t)gridDim.x * blockDim.x) {
+        double ss = 0.0;
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * nper + i;
+            const double t = (double)(vp[k] + sigma * v[k]);
+            ss += t * t;
+        }
+        const T a = (T)sqrt(ss) / sigma;
+        T fac = T(1);
+        // 1 - max(a - c, 0) / a written as min(c, a) / a: the same number without the cancellation that costs fp32 three
+        // digits when the threshold c = lam w / sigma is small against a (the reference computes this in fp64 only)
+        if (a != T(0)) fac = fmin(lam * w[i] / sigma, a) / a;
+        for (int b = 0; b < nband; ++b) {
+            const size_t k = (size_t)b * nper + i;
+            const T vt = vp[k] + sigma * v[k];
+            v[k] = (a != T(0)) ? vt * fac : vt;
+        }
+    }
+}
+
 // x = xp - tau (xout + g) ; positivity ; norm_diff partials + any(x)   (primal_dual.py:139-150)
 // xprev (optional): xout is formed as 2 xout - xprev on the fly -- with a LINEAR synthesis psi^H(2 v - vp) =
 // 2 psi^H(v) - psi^H(vp), and psi^H(vp) is the previous iteration's psi^H(v): the coefficient cube 2 v - vp
@@ -2159,6 +2203,34 @@ int pfb_dual_apply_chunk(int dtype, const void* vp, void* v, const void* weight,
 int pfb_dual_apply(int dtype, const void* vp, void* v, const void* weight, const void* sum_in, double lam,
                    double sigma, int nband, size_t nper, void* vp_out, void* stream) {
     return pfb_dual_apply_chunk(dtype, vp, v, weight, sum_in, lam, sigma, nband, nper, nper, vp_out, stream);
+}
+
+int pfb_prox_21(int dtype, const void* v, void* result, const void* weight, double lam, double sigma,
+                int nband, size_t nper, void* stream) {
+    PFB_REQUIRE(v && result && weight && nband > 0 && sigma != 0.0, PFB_ERR_INVALID, "prox_21: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_prox_21_l2<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)v, (float*)result,
+                           (const float*)weight, (float)lam, (float)sigma, nband, nper);
+    else
+        hipLaunchKernelGGL((k_prox_21_l2<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)v, (double*)result,
+                           (const double*)weight, lam, sigma, nband, nper);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
+}
+
+int pfb_dual_update_l2(int dtype, const void* vp, void* v, const void* weight, double lam, double sigma,
+                       int nband, size_t nper, void* stream) {
+    PFB_REQUIRE(vp && v && weight && nband > 0 && sigma != 0.0, PFB_ERR_INVALID, "dual_update_l2: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (dtype == PFB_F32)
+        hipLaunchKernelGGL((k_dual_update_l2<float>), dim3(ew_grid(nper)), dim3(256), 0, st, (const float*)vp, (float*)v,
+                           (const float*)weight, (float)lam, (float)sigma, nband, nper);
+    else
+        hipLaunchKernelGGL((k_dual_update_l2<double>), dim3(ew_grid(nper)), dim3(256), 0, st, (const double*)vp, (double*)v,
+                           (const double*)weight, lam, sigma, nband, nper);
+    PFB_HIP_CHECK(hipGetLastError());
+    return PFB_OK;
 }
 
 int pfb_prox_21m(int dtype, const void* v, void* result, const void* weight, double lam, double sigma,

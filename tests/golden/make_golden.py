@@ -33,6 +33,7 @@ from pfb.operators.psi import Psi  # noqa: E402
 from pfb.prox.prox_21m import (prox_21m, prox_21m_numba, dual_update,  # noqa: E402
                                dual_update_numba)
 from pfb.prox.prox_21 import prox_21  # noqa: E402
+from pfb.prox.prox_21 import prox_21_numba as prox_21_numba_l2, dual_update_numba as dual_update_numba_l2  # noqa: E402
 from pfb.deconv.clark import clark, subminor  # noqa: E402
 from pfb.deconv.hogbom import hogbom  # noqa: E402
 import scipy.fft as sfft  # noqa: E402
@@ -238,6 +239,15 @@ def gen_prox():
         out[f'g{g}_dual_update_numba'] = vv
         out[f'g{g}_prox21m'] = prox_21m(v, lam, weight=w)
         out[f'g{g}_prox21'] = prox_21(v, lam, weight=w)
+        # the band-l2-NORM variants of prox/prox_21.py (:23-48 prox_21_numba, :62-88 dual_update_numba): their arrays are
+        # (nband, nbasis, ntot) with the coefficient plane flattened
+        v3, vp3, w3 = v.reshape(nband, nbasis, -1), vp.reshape(nband, nbasis, -1), w.reshape(nbasis, -1)
+        res = np.full(v3.shape, np.nan)
+        prox_21_numba_l2(v3, res, lam, sigma=sigma, weight=w3)
+        out[f'g{g}_prox21_numba'] = res
+        vv = v3.copy()
+        dual_update_numba_l2(vp3, vv, lam, sigma=sigma, weight=w3)
+        out[f'g{g}_dual_update_numba_l2'] = vv
     np.savez_compressed(os.path.join(HERE, 'prox.npz'), **out)
     print('prox.npz', len(out))
 

@@ -278,6 +278,17 @@ def test_prox_golden(amd, golden, rdt):
         assert maxerr(vv, ref) <= rtol * np.abs(ref).max(), (i, 'dual')
         assert maxerr(amd.p21m.prox_21m(v, lam, weight=w), g[f'g{i}_prox21m']) <= rtol * 10
         assert maxerr(amd.p21.prox_21(v, lam, weight=w), g[f'g{i}_prox21']) <= rtol * 10
+        # band-l2-norm variants (prox/prox_21.py:23-48, 62-88), the reference's flattened (nband, nbasis, ntot) shapes
+        nb_, nbas = v.shape[:2]
+        v3, vp3, w3 = v.reshape(nb_, nbas, -1), vp.reshape(nb_, nbas, -1), w.reshape(nbas, -1)
+        r3 = np.full(v3.shape, np.nan, dtype=rdt)
+        assert amd.p21.prox_21_numba(v3, r3, lam, sigma=sigma, weight=w3) is r3
+        ref = g[f'g{i}_prox21_numba']
+        assert maxerr(r3, ref) <= rtol * max(np.abs(ref).max(), 1e-30), (i, 'prox21_numba')
+        vv3 = v3.copy()
+        amd.p21.dual_update_numba(vp3, vv3, lam, sigma=sigma, weight=w3)
+        ref = g[f'g{i}_dual_update_numba_l2']
+        assert maxerr(vv3, ref) <= rtol * np.abs(ref).max(), (i, 'dual l2')
 
 
 @pmp("nband", [1, 3, 6])

@@ -265,6 +265,15 @@ def test_prox_matches_reference(golden):
         assert_allclose(vv, g[f'g{i}_dual_update_numba'], rtol=1e-13, atol=1e-14)
         assert_allclose(px.prox_21m(v, lam, weight=w), g[f'g{i}_prox21m'], rtol=1e-13, atol=1e-15)
         assert_allclose(px.prox_21(v, lam, weight=w), g[f'g{i}_prox21'], rtol=1e-13, atol=1e-15)
+        # the band-l2-norm numba variants of prox/prox_21.py (arrays with the coefficient plane flattened)
+        nb_, nbas = v.shape[:2]
+        v3, vp3, w3 = v.reshape(nb_, nbas, -1), vp.reshape(nb_, nbas, -1), w.reshape(nbas, -1)
+        r3 = np.full(v3.shape, np.nan)
+        px.prox_21_numba(v3, r3, lam, sigma=sigma, weight=w3)
+        assert_allclose(r3, g[f'g{i}_prox21_numba'], rtol=1e-13, atol=1e-15)
+        vv3 = v3.copy()
+        px.dual_update_numba_l2(vp3, vv3, lam, sigma=sigma, weight=w3)
+        assert_allclose(vv3, g[f'g{i}_dual_update_numba_l2'], rtol=1e-13, atol=1e-14)
         # reference tests/test_psi_operator.py:126-147
         assert_allclose(px.prox_21m(v / sigma, lam / sigma, weight=w), res, atol=1e-8)
 
