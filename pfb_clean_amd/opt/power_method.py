@@ -8,6 +8,11 @@ HessianPsf (or the functools.partial of hessian_psf_cube / _hessian_psf_slice th
 RNG exactly like the reference (np.random.randn, fp64); `dtype` (numpy or torch dtype,
 an extension) casts it and, when a torch dtype, keeps the iteration on device tensors.
 A is called with the same array kind (numpy / GPU tensor) as the start vector.
+
+Extension `group` (the reference's power_method_dist, power_method.py:70-116, sums the same three numbers
+over its dask workers): a torch.distributed process group over which the BAND axis is sharded.  `A`, `imsize` / `b0`
+then describe this rank's bands; <bp,b>, <bp,bp>, <b,b> are all-reduced (three scalars per iteration, one collective)
+and every rank returns the same beta together with its own bands of the eigenvector.
 """
 import math
 import sys
@@ -19,8 +24,19 @@ from .. import _lib, _dev
 
 
 def power_method(A, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1, report_freq=25,
-                 dtype=None):
+                 dtype=None, group=None):
     lib = _lib.load()
+    if group is not None:
+        import torch.distributed as dist
+        pg = None if group is True else group
+
+    def allsum(vals):                   # sum of a short list of host scalars over the band shards
+        if group is None:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device=bd.device if dist.get_backend(pg) != 'gloo' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+        return t.tolist()
+
     if b0 is None:
         b0 = np.random.randn(*imsize)
         if isinstance(dtype, torch.dtype):
@@ -58,7 +74,7 @@ def power_method(A, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1, report_fr
     def scale(v, s):
         _lib.check(lib.pfb_axpby(code, 0.0, _dev.ptr(v), float(s), _dev.ptr(v), n, _dev.stream()))
 
-    scale(bd, 1.0 / math.sqrt(dot(bd, bd)))
+    scale(bd, 1.0 / math.sqrt(allsum([dot(bd, bd)])[0]))
     bp = bd.clone()
     b = bd
     beta, eps, k = 1.0, 1.0, 0
@@ -73,14 +89,14 @@ def power_method(A, imsize, b0=None, tol=1e-5, maxit=250, verbosity=1, report_fr
                     _dev.ptr(out), _dev.stream()))                 # out[0] = <bp, b>, out[2] = <b, b>
             b = bout
             dot_into(bp, bp, 1)
-            pb, pp, bb = out[:3].tolist()
+            pb, pp, bb = allsum(out[:3].tolist())
         else:
             res = A(bp.cpu().numpy()) if as_numpy else A(bp)
             b = _dev.to_dev(res, bp.dtype).contiguous()
             dot_into(bp, b, 0)
             dot_into(bp, bp, 1)
             dot_into(b, b, 2)
-            pb, pp, bb = out[:3].tolist()                          # ONE host look per iteration
+            pb, pp, bb = allsum(out[:3].tolist())                  # ONE host look per iteration
         bnorm = math.sqrt(bb)
         betap = beta
         beta = pb / pp

@@ -445,6 +445,13 @@ def _pcg_rank(rank, world, port, q):
         for tag, kw in (('fixed', dict(tol=0.0, maxit=10, minit=10)), ('stop', dict(tol=2e-2, maxit=60, minit=3))):
             x, _, r = pcg_fused(A, bt, None, mdiv=sigmainv, distributed=True, **kw)
             res[tag] = (x.cpu().numpy(), r.iters)
+        # band-sharded power method (reference power_method_dist, power_method.py:70-116): the three inner
+        # products summed over the ranks, every rank the same beta
+        from pfb_clean_amd.opt.power_method import power_method
+        b0 = np.random.default_rng(77).standard_normal((nband, nx, ny))
+        beta, vec = power_method(A, (nb, nx, ny), b0=torch.from_numpy(b0[sl]).to(dev), tol=1e-9, maxit=40, verbosity=0,
+                                 group=True)
+        res['pm'] = (beta, vec.cpu().numpy())
         q.put((rank, band0, nb, res))
     finally:
         dist.destroy_process_group()
@@ -468,6 +475,8 @@ def test_band_sharded_cube_pcg_two_ranks_one_gpu():
     for tag, kw in (('fixed', dict(tol=0.0, maxit=10, minit=10)), ('stop', dict(tol=2e-2, maxit=60, minit=3))):
         tr = osv.PCGTrace()
         ref[tag] = (osv.pcg(oA, beam * b, None, M=lambda v: v / sigmainv, trace=tr, **kw), len(tr.eps))
+    b0 = np.random.default_rng(77).standard_normal(b.shape)
+    beta_ref, vec_ref = osv.power_method(oA, b.shape, b0=b0, tol=1e-9, maxit=40, verbosity=0)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -484,6 +493,9 @@ def test_band_sharded_cube_pcg_two_ranks_one_gpu():
             xr, kref = ref[tag]
             assert iters == kref, (tag, iters, kref)
             assert np.abs(x - xr[band0:band0 + nb]).max() < 1e-9 * np.abs(xr).max(), (rank, tag)
+        beta, vec = res['pm']
+        assert abs(beta - beta_ref) < 1e-10 * abs(beta_ref), (rank, beta, beta_ref)
+        assert np.abs(vec - vec_ref[band0:band0 + nb]).max() < 1e-9 * np.abs(vec_ref).max(), rank
 
 
 @pytest.mark.parametrize('rdt', [np.float64, np.float32])
