@@ -276,7 +276,7 @@ def extra_configs(ctx):
     try:
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), PFB_COMM_TIMEOUT_S='60')
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
         if p.returncode != 0 or not line:
             raise RuntimeError(f"rc={p.returncode}: {p.stderr[-200:]}")
