@@ -2106,11 +2106,22 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             [[maybe_unused]] const V2* xr_e = reinterpret_cast<const V2*>(x + rowoff) + t;
             [[maybe_unused]] const V2* br_e = BEAM ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
             [[maybe_unused]] const V2* dr_e = MODE == 2 ? reinterpret_cast<const V2*>(dot_with2 + rowoff) + t : nullptr;
+            if constexpr (!OPF) {
+                // operands read in place: combine the two parities FIRST (no load involved), so that the even-bin result
+                // is dead before the operand streams start -- 32 registers less across the loop below
+#pragma unroll
+                for (int j = 0; j < E; ++j) vv[j] = ev[j] + mulc(vv[j], P::tw_row(ltm, t, j));
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                cplx<T> e0;
-                if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
-                const cplx<T> zz = e0 + mulc(vv[j], P::tw_row(ltm, t, j));
+                cplx<T> zz;
+                if constexpr (!OPF) zz = vv[j];
+                else {
+                    cplx<T> e0;
+                    if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
+                    zz = e0 + mulc(vv[j], P::tw_row(ltm, t, j));
+                }
                 V2 val;
                 V2 xx;
                 [[maybe_unused]] V2 bb;
@@ -2682,11 +2693,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
     if constexpr (InvP<T, L, EP>::OK) {
         // pipelined persistent kernel: no beam, inner products only against x itself (+ dot_with2)
         const bool plain_dots = !dot_with || (dot_with == x);
-        // (4096-point rows at 16 elements per thread, operands read in place: the beam-and-two-dots epilogue of the PCG
-        // call needs 5 registers more than the 128 a 1024-thread workgroup gets -- 152 B of scratch inside a kernel whose
-        // point is loads in flight; that one combination stays on the plain kernel)
-        const bool regs_ok = InvP<T, L, EP>::OPF || sizeof(T) == 8 || !(beam && dot_with2);  // (512-thread fp64 tiles have 256 registers)
-        if (ft->inv_persistent && plain_dots && regs_ok && !(dot_with2 && !dot_with)) {
+        if (ft->inv_persistent && plain_dots && !(dot_with2 && !dot_with)) {
             using IP = InvP<T, L, EP>;
             const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
             const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
