@@ -190,6 +190,49 @@ def test_persistent_row_kernels_multi_tile(amd, mode, ny, with_beam):
 
 
 @pmp('with_beam', [False, True])
+@pmp('rdt', [np.float32, np.float64])
+@pmp('mode', [0, 2])
+def test_persistent_row_kernels_8192_pixel_rows(amd, mode, rdt, with_beam):
+    """ny = 8192 (4096-point rows, round 3): fp32 takes the 4-row small-table tiles of k_row_fwd_pow2q / k_row_inv_pow2p
+    (16 elements per thread, operands read in place, two-loop epilogue -- also for the beam + two-dots call of the PCG on
+    embedded plans), fp64 the plain forward kernel and the 2-row 512-thread inverse tile with its own pass table; 512
+    rows x 2 bands = several tiles per workgroup across a band boundary.  Against the oracle."""
+    from pfb_clean_amd import _lib, _dev
+    rng = np.random.default_rng(33)
+    nb, nx, ny = 2, 512, 8192
+    P, Q = 2 * nx, 2 * ny
+    psfhat = ofc.psfhat_from_psf(rng.standard_normal((nb, P, Q)))
+    x = rng.standard_normal((nb, nx, ny)).astype(rdt)
+    w = rng.standard_normal((nb, nx, ny)).astype(rdt)
+    beam = (0.5 + rng.random((nb, nx, ny))).astype(rdt) if with_beam else None
+    xpad, xhat, xout = ofc.make_scratch(psfhat, Q, x.shape, np.float64)
+    ref = ofc.hessian_psf_cube(xpad, xhat, xout, None if beam is None else beam.astype(np.float64), psfhat, Q,
+                               x.astype(np.float64), sigmainv=0.3, wsum=1.7)
+    dev = torch.device('cuda')
+    plan = amd.psf.PsfConvPlan(torch.from_numpy(psfhat.astype(cdt(rdt))).to(dev), nx, ny, Q)
+    assert plan.fast_path
+    xt, wt = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    bt = None if beam is None else torch.from_numpy(beam).to(dev)
+    out = torch.empty_like(xt)
+    dots = torch.zeros(3, dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    if mode == 0:
+        plan.apply(xt, out=out, beam=bt, wsum=1.7, sigmainv=0.3)
+    else:
+        _lib.check(lib.pfb_psfconv_apply_dots(plan._h, 0, nb, _dev.ptr(xt), _dev.ptr(bt), 1.7, 0.3, _dev.ptr(out),
+                                              _dev.ptr(xt), _dev.ptr(wt), _dev.ptr(dots), _dev.stream()))
+    o = out.cpu().numpy().astype(np.float64)
+    assert relerr(o, ref) < TOL_CONV[rdt]
+    if mode:
+        d = dots.cpu().numpy()
+        tol = 1e-9 if rdt == np.float32 else 1e-12
+        assert abs(d[0] - np.vdot(x.astype(np.float64), o)) < tol * np.linalg.norm(o) * np.linalg.norm(x)
+        assert abs(d[1] - np.vdot(w.astype(np.float64), o)) < tol * np.linalg.norm(o) * np.linalg.norm(w)
+        assert abs(d[2] - np.vdot(o, o)) < tol * np.vdot(o, o)
+    plan.close()
+
+
+@pmp('with_beam', [False, True])
 def test_persistent_row_inverse_fp64_multi_tile(amd, with_beam):
     """fp64 at ny = 4096: two-row tiles, 512-thread workgroups, even-bin result kept in registers,
     32-byte pieces XCD-grouped four to a line (k_row_inv_pow2p<double>); 8 tiles per workgroup, all
