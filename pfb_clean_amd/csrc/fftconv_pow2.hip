@@ -1749,7 +1749,12 @@ struct InvP {
     // one such workgroup per CU every thread may use 256 VGPRs, so the even-bin result stays in registers
     // (PARK = false) and the prefetched pieces / operands fit as well.
     static constexpr bool PARK = sizeof(T) == 4 && E < 16;     // (E = 16: eight rows fill the LDS, the even-bin result stays in registers)
-    static constexpr int G = (sizeof(T) == 4 ? 1024 : 512) / F::TPB;
+#ifndef PFB_INV_HALF
+#define PFB_INV_HALF 0          // experiment: fp32 16-element tiles on 512 threads, two workgroups per CU (de-phased barriers)
+#endif
+    static constexpr bool HALF = PFB_INV_HALF && sizeof(T) == 4 && E >= 16 && L == 2048;
+    static constexpr int WG_PER_CU = HALF ? 2 : 1;
+    static constexpr int G = (sizeof(T) == 4 && !HALF ? 1024 : 512) / F::TPB;
     static constexpr int NT = G * F::TPB;
     static constexpr int STRIDE = F::LDS_ELEMS + 4;
     static constexpr int NVB = FastCfg<T>::NVB;
@@ -1765,7 +1770,7 @@ struct InvP {
     // NOT prefetched into registers (vv + ev + the strided pieces already take 100 of the 128) but read where they are
     // used; what the persistent kernel still buys over the plain one are the tables loaded once and the strided pieces of
     // the next phase / next tile in flight during every transform.
-    static constexpr bool SMT = E >= 16 && (L >= 4096 || sizeof(T) == 8);
+    static constexpr bool SMT = E >= 16 && (L >= 4096 || sizeof(T) == 8 || HALF);
     static constexpr bool OPF = E < 16;
     // NXT: the NEXT tile's even-bin pieces are requested during the odd-bin transform and stay in flight across the
     // epilogue (always with OPF; without it only where registers remain: the 512-thread fp64 tiles have 256)
@@ -1776,14 +1781,20 @@ struct InvP {
     // NXE: neither -- but the next tile's even-bin pieces are requested at the START of the epilogue (the transforms are
     // over, their temporaries gone) instead of at the top of the next trip, where they were waited for right away
     // (profiles/r03_q_phase_stamps_8192x2_*: 8.4 us of a 45 us trip)
+#ifndef PFB_INV_HOIST_B
+#define PFB_INV_HOIST_B 8
+#endif
 #ifndef PFB_INV_NXE
 #define PFB_INV_NXE 0           // measured: 1.955 vs 1.639 ms per 2 x 8192^2 fp64 (the pieces queue behind the epilogue's own loads): off
 #endif
-    static constexpr bool NXE = !NXT && PFB_INV_NXE && sizeof(T) == 8;      // (fp32 at 128 registers: 52-132 B of scratch)
+    static constexpr bool NXE = !NXT && PFB_INV_NXE && (sizeof(T) == 8 || PFB_INV_NXE > 1);
+    // HOIST (fp32 NXE): all operand rows of the tile requested at once behind the combine loop (the even-bin result is dead
+    // by then), the next tile's even-bin pieces half way through the loop that consumes them, in the registers it has freed
+    static constexpr bool HOIST = NXE && sizeof(T) == 4;
     static constexpr int NTM = SMT ? F::TPB : L;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
-                               (sizeof(T) == 4 ? (NT == 1024 && G >= 4 && G <= 16) : (NT == 512 && (G == 2 || G == 4) && L >= 1024));
+                               (sizeof(T) == 4 ? (NT == (HALF ? 512 : 1024) && G >= 4 && G <= 16) : (NT == 512 && (G == 2 || G == 4) && L >= 1024));
     __device__ __forceinline__ static cplx<T> tw_row(const cplx<T>* ltm, int t, int j) {     // w_M^(t + TPB j)
         if constexpr (SMT) return j == 0 ? ltm[t] : ltm[t] * root32<T>(j);
         else return ltm[t + F::TPB * j];
@@ -1804,6 +1815,17 @@ template <typename T, int L> struct InvPE {
 #ifndef PFB_INV_LIN
 #define PFB_INV_LIN 1
 #endif
+#ifndef PFB_INV_ABL             // ablation builds of k_row_inv_pow2p (timing only, results are wrong): 1 no strided pieces,
+#define PFB_INV_ABL 0           // 2 no operand rows, 4 no result stores, 8 no transforms
+#endif
+template <int NP, typename H> __device__ __forceinline__ void abl_hooks(H&& h) {
+    if constexpr (NP > 0) { abl_hooks<NP - 1>(h); h(std::integral_constant<int, NP - 1>{}); }
+}
+template <typename F, typename V, typename C, typename H>
+__device__ __forceinline__ void inv_run(V& vv, C* lds, int t, const C* ltw, H&& h) {
+    if constexpr ((PFB_INV_ABL & 8) != 0) abl_hooks<F::NPASS>(h);
+    else F::template run<true>(vv, lds, t, ltw, h);
+}
 // strength-reduced addressing of the strided pieces (see fwdp_post_lin): the blocks of a thread are BSTEP apart, so the
 // load address is a workgroup-uniform base (band, parity, step) + a 32-bit per-thread offset that never changes, and
 // the padded LDS index of the scatter is one base + compile-time offsets.  Regular whenever BSTEP divides the odd-bin
@@ -1824,6 +1846,12 @@ __device__ __forceinline__ void inv_issue(const cplx<T>* __restrict__ Tb, int nx
                                           Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
     using P = InvP<T, L, E>;
     constexpr int NBP = PAR ? P::NBO : P::NBE, NIT = PAR ? P::NITO : P::NITE;
+    if constexpr ((PFB_INV_ABL & 1) != 0) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            for (int c = 0; c < P::NVB; ++c) y[k].c[c] = cplx<T>((T)(bi + k), (T)rr);
+        return;
+    }
     if constexpr (inv_lin_ok<T, L, E>()) {
         inv_issue_slice<T, L, E, PAR, 0, NIT>(Tb, nx, i0, rr, bi, y);
         return;
@@ -1843,6 +1871,12 @@ __device__ __forceinline__ void inv_issue_slice(const cplx<T>* __restrict__ Tb, 
                                                 Blk<T, FastCfg<T>::NVB> (&y)[InvP<T, L, E>::NITE]) {
     using P = InvP<T, L, E>;
     constexpr int NBP = PAR ? P::NBO : P::NBE;
+    if constexpr ((PFB_INV_ABL & 1) != 0) {
+#pragma unroll
+        for (int k = K0; k < K1; ++k)
+            for (int c = 0; c < P::NVB; ++c) y[k].c[c] = cplx<T>((T)(bi + k), (T)rr);
+        return;
+    }
     if constexpr (inv_lin_ok<T, L, E>()) {
         const cplx<T>* ub = Tb + (size_t)(PAR ? P::NBE : 0) * nx * P::NVB;                    // workgroup-uniform
         const size_t ustep = (size_t)P::BSTEP * nx * P::NVB;
@@ -1932,7 +1966,7 @@ __device__ __forceinline__ void inv_build(const cplx<T>* lds, const cplx<T>* ltm
 //     IFFT (even)  <- y(odd bins of this tile), then x [, beam]   of this tile's rows
 //     IFFT (odd)   <- dot_with2 rows, then y(even bins of the NEXT tile)
 template <typename T, int L, int E, int MODE, bool BEAM, bool SPR = false>
-__global__ void __launch_bounds__((InvP<T, L, E>::NT))
+__global__ void __launch_bounds__((InvP<T, L, E>::NT), (InvP<T, L, E>::NT / 256 * InvP<T, L, E>::WG_PER_CU))
 k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const cplx<T>* __restrict__ ptw, const T* __restrict__ x, const T* __restrict__ beam,
                 const T* __restrict__ dot_with2, T* __restrict__ out,
@@ -2008,12 +2042,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
                 const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
                 const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + rowoff) + t : nullptr;
-                F::template run<true>(vv, lds, t, ltw, [&](auto k) {
+                inv_run<F>(vv, lds, t, ltw, [&](auto k) {
                     constexpr int K = decltype(k)::value;
                     if constexpr (P::PARK) {
                         if (dst && oprev) {
 #pragma unroll
-                            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) oprev[TPB * j] = ov[j];
+                            for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) { if (!(PFB_INV_ABL & 4) || scale == (T)123456) oprev[TPB * j] = ov[j]; }
                         }
                     }
                     if constexpr (K < NPA) {            // first passes: the odd-bin pieces (needed first)
@@ -2022,7 +2056,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                         constexpr int KK = K - NPA;
 #pragma unroll
                         for (int j = (KK * E) / NPB; j < ((KK + 1) * E) / NPB; ++j) {
-                            xq[j] = xr[TPB * j];
+                            if constexpr ((PFB_INV_ABL & 2) == 0) xq[j] = xr[TPB * j]; else { xq[j].x = (T)(t + j); xq[j].y = (T)1; }
                             if constexpr (BEAM) bq[j] = br[TPB * j];
                         }
                     }
@@ -2069,12 +2103,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             inv_build<T, L, E, 1>(lds, ltm, wq1, t, vv);
             STAMP(2, sit, 9);
             if constexpr (SPR) {
-                F::template run<true>(vv, lds, t, ltw, [&](auto k) {
+                inv_run<F>(vv, lds, t, ltw, [&](auto k) {
                     constexpr int K = decltype(k)::value;
                     if constexpr (MODE == 2 && OPF) {
                         if constexpr (K < NPA) {        // dot_with2 rows first: the epilogue waits for them
 #pragma unroll
-                            for (int j = (K * E) / NPA; j < ((K + 1) * E) / NPA; ++j) rq[j] = dr2[TPB * j];
+                            for (int j = (K * E) / NPA; j < ((K + 1) * E) / NPA; ++j) { if constexpr ((PFB_INV_ABL & 2) == 0) rq[j] = dr2[TPB * j]; else { rq[j].x = (T)(t - j); rq[j].y = (T)2; } }
                         } else {                        // the next tile's even-bin pieces stay in flight past the epilogue
                             constexpr int KK = K - NPA;
                             inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
@@ -2088,7 +2122,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             }
             STAMP(2, sit, 10);
         }
-        if constexpr (P::NXE) {
+        if constexpr (P::NXE && !P::HOIST) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, tid % G, tid / G, y);
         }
@@ -2113,6 +2147,8 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 for (int j = 0; j < E; ++j) vv[j] = ev[j] + mulc(vv[j], P::tw_row(ltm, t, j));
                 __builtin_amdgcn_sched_barrier(0);
             }
+            [[maybe_unused]] V2 xh[P::HOIST ? E : 1], rh[(P::HOIST && MODE == 2) ? E : 1], bh[(P::HOIST && BEAM) ? E : 1];
+
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 cplx<T> zz;
@@ -2122,10 +2158,28 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
                     zz = e0 + mulc(vv[j], P::tw_row(ltm, t, j));
                 }
+                if constexpr (P::HOIST) {
+                    // operand rows in batches of HB samples; behind the LAST batch the next tile's even-bin pieces (in order:
+                    // nothing the epilogue still waits for is queued behind them)
+                    constexpr int HB = PFB_INV_HOIST_B;
+                    if (j % HB == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = j; q < j + HB && q < E; ++q) {
+                            xh[q] = xr_e[TPB * q];
+                            if constexpr (MODE == 2) rh[q] = dr_e[TPB * q];
+                            if constexpr (BEAM) bh[q] = br_e[TPB * q];
+                        }
+                        if (j + HB >= E)
+                            inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, tid % G, tid / G, y);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
                 V2 val;
                 V2 xx;
                 [[maybe_unused]] V2 bb;
                 if constexpr (OPF) { xx = xq[j]; if constexpr (BEAM) bb = bq[j]; }
+                else if constexpr (P::HOIST) { xx = xh[j]; if constexpr (BEAM) bb = bh[j]; }
                 else { xx = xr_e[TPB * j]; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 if constexpr (BEAM) {
                     val.x = zz.x * scale * bb.x + sigmainv * xx.x;
@@ -2138,12 +2192,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 else orow[TPB * j] = val;
                 // operands read in place (!OPF): a few samples at a time, or every x / dot_with2 load of the tile is
                 // hoisted to the top of the loop and spills
-                if constexpr (!OPF) { if (sizeof(T) == 4 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (!OPF && !P::HOIST) { if (sizeof(T) == 4 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
                         V2 d2;
-                        if constexpr (OPF) d2 = rq[j]; else d2 = dr_e[TPB * j];
+                        if constexpr (OPF) d2 = rq[j]; else if constexpr (P::HOIST) d2 = rh[j]; else d2 = dr_e[TPB * j];
                         acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
                     }
                     acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
@@ -2696,7 +2750,7 @@ static void launch_row_inv(pfb_conv_plan* p, const FastTables* ft, int band0, in
         if (ft->inv_persistent && plain_dots && !(dot_with2 && !dot_with)) {
             using IP = InvP<T, L, EP>;
             const int tiles_per_band = p->nx / IP::G, ntiles = tiles_per_band * nb;
-            const int grid = ntiles < ft->num_cu ? ntiles : ft->num_cu;
+            const int grid = ntiles < IP::WG_PER_CU * ft->num_cu ? ntiles : IP::WG_PER_CU * ft->num_cu;
             const long double a = 6.283185307179586476925286766559005768L / (2.0L * (long double)p->ny);
             const cplx<T> wq1((T)cosl(a), (T)(-sinl(a)));
             static const bool spread = [] { const char* e = getenv("PFB_SPREAD"); return !e || atoi(e); }();
