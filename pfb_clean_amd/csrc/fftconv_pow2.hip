@@ -131,7 +131,13 @@ constexpr int LDS_BUDGET = 152 * 1024;
 // size needs a 1024-thread workgroup (128-VGPR cap) and spilled ~200 bytes per lane: 4.32 -> 3.29 ms
 // per 2 bands.  (fp32 at 8192 is the other way round: E = 16 under its 4-waves/SIMD launch bound
 // spills 788 bytes, 2.22 -> 3.58 ms, and still 2.66 ms with a 2-waves/SIMD bound and 84 bytes.)
-template <typename T, int H> constexpr int ecol() { return (H >= 8192 && sizeof(T) == 8) ? 16 : FastCfg<T>::ECOL; }
+// ... and 4 up to H = 1024 (the plain, non-persistent column kernel): at these sizes a launch is ONE wave of workgroups, each a
+// serial chain of four transforms; twice the threads per column halve the chain (1024^2 x 8 fp32: col 93.8 -> 73.2 us,
+// 1024^2 x 1: 23.6 -> 18.1, fp64 27.6 -> 24.1; profiles/r03_ab_col_e4_small.md)
+#ifndef PFB_COL_E4_MAXH
+#define PFB_COL_E4_MAXH 1024
+#endif
+template <typename T, int H> constexpr int ecol() { return (H >= 8192 && sizeof(T) == 8) ? 16 : (H <= PFB_COL_E4_MAXH && H >= 64 ? 4 : FastCfg<T>::ECOL); }
 
 // rows per workgroup for the row kernels
 template <typename T, int L, int E, int GMAX>
