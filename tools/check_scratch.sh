@@ -12,7 +12,7 @@ $CXX -c cgvec.hip -o $T/cg.o 2> $T/cg.log &
 $CXX -mllvm -amdgpu-sched-strategy=max-ilp -c wavelet.hip -o $T/wv.o 2> $T/wv.log &
 wait
 cd ../..
-PAT='k_row_fwd_pow2q<float, 2048, false>|k_col_pow2p<float, 4096, 8, true, true, true>|k_row_inv_pow2p<float, 2048, 8, 2, false, true>|k_pcg_update_dir<(float|double), ., 2, true, true>|k_row_fwd_pow2<float, (512|1024), (8|16)>|k_col_pow2<float, 1024, 8>|k_row_inv_pow2<float, 512, 8>|k_col_pow2p<float, 2048, 8, false, true, (true|false)>|k_row_inv_pow2p<float, 1024, 8, 0, false, true>|k_row_fwd_pow2<double, 4096, 8>|k_col_pow2x<double, 8192, 8, true, true>|k_row_inv_pow2p<double, 4096, 16, 2, false, true>|k_col_pow2x<float, 8192, 8, true, true>|k_row_fwd_pow2q<float, 4096, false>|k_row_inv_pow2p<float, 4096, 16, 2, false, true>|k_dual_update_vec<float, 4, true>|k_dwt_l1_fused<float|k_idwt_finest_fused2<float|k_pd_primal_vec<float, 4>|k_dwt_batched<float|k_idwt_batched2<float'
+PAT='k_row_fwd_pow2q<float, 2048, false>|k_col_pow2p<float, 4096, 8, true, true, true>|k_row_inv_pow2p<float, 2048, 8, 2, false, true>|k_pcg_update_dir<(float|double), ., 2, true, true>|k_row_fwd_pow2<float, (512|1024), (8|16)>|k_col_pow2<float, 1024, 4>|k_row_inv_pow2<float, 512, 8>|k_col_pow2p<float, 2048, 8, false, true, (true|false)>|k_row_inv_pow2p<float, 1024, 8, 0, false, true>|k_row_fwd_pow2<double, 4096, 8>|k_col_pow2x<double, 8192, 8, true, true>|k_row_inv_pow2p<double, 4096, 16, 2, false, true>|k_col_pow2x<float, 8192, 8, true, true>|k_row_fwd_pow2q<float, 4096, false>|k_row_inv_pow2p<float, 4096, 16, 2, false, true>|k_dual_update_vec<float, 4, true>|k_dwt_l1_fused<float|k_idwt_finest_fused2<float|k_pd_primal_vec<float, 4>|k_dwt_batched<float|k_idwt_batched2<float'
 {
   echo "# kernel resources of the BASELINE configs' kernels (\`tools/check_scratch.sh\`: hipcc -Rpass-analysis=kernel-resource-usage)"
   echo; echo '```'
