@@ -1821,6 +1821,13 @@ template <typename T, int L> struct InvPE {
 #ifndef PFB_INV_LIN
 #define PFB_INV_LIN 1
 #endif
+// PFB_INV_EARLY bit 0: the first pass's slice of loads (odd-bin pieces / dot_with2 rows) is requested right behind the scatter
+// instead, so that something is in flight across the barrier and inv_build: 0.6075 -> 0.5999 ms per 8 x 4096^2 fp32, 0.7415 ->
+// 0.7216 per 4 x 4096^2 fp64.  Bits 1-3 (all odd-bin pieces there / x rows behind the even transform / next tile's pieces in the
+// last pass only) measured no better (profiles/r03_ab_inv_ablation.md).
+#ifndef PFB_INV_EARLY
+#define PFB_INV_EARLY 1
+#endif
 #ifndef PFB_INV_ABL             // ablation builds of k_row_inv_pow2p (timing only, results are wrong): 1 no strided pieces,
 #define PFB_INV_ABL 0           // 2 no operand rows, 4 no result stores, 8 no transforms
 #endif
@@ -2040,6 +2047,8 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             inv_scatter<T, L, E, 0>(y, lds0 + (size_t)rr * P::STRIDE, bi);
             STAMP(2, sit, 2);
             if constexpr (!SPR) inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
+            else if constexpr ((PFB_INV_EARLY & 2) != 0) inv_issue<T, L, E, 1>(Tb, d.nx, i0, rr, bi, y);
+            else if constexpr ((PFB_INV_EARLY & 1) != 0) inv_issue_slice<T, L, E, 1, 0, P::NITO / NPA>(Tb, d.nx, i0, rr, bi, y);   // pass 0's slice: in flight across the barrier and inv_build
             __syncthreads();
             STAMP(2, sit, 3);
             inv_build<T, L, E, 0>(lds, ltm, wq1, t, vv);
@@ -2057,8 +2066,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                         }
                     }
                     if constexpr (K < NPA) {            // first passes: the odd-bin pieces (needed first)
+                        if constexpr (!((PFB_INV_EARLY & 1) && K == 0) && !(PFB_INV_EARLY & 2))
                         inv_issue_slice<T, L, E, 1, (K * P::NITO) / NPA, ((K + 1) * P::NITO) / NPA>(Tb, d.nx, i0, rr, bi, y);
-                    } else if constexpr (OPF) {         // then this tile's x (and beam) rows for the epilogue
+                    } else if constexpr (OPF && !(PFB_INV_EARLY & 4)) {         // then this tile's x (and beam) rows for the epilogue
                         constexpr int KK = K - NPA;
 #pragma unroll
                         for (int j = (KK * E) / NPB; j < ((KK + 1) * E) / NPB; ++j) {
@@ -2071,6 +2081,15 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 F::template run<true>(vv, lds, t, ltw);
             }
             STAMP(2, sit, 5);
+            if constexpr (SPR && OPF && (PFB_INV_EARLY & 4) != 0) {      // x rows requested here: in flight across park, scatter, build
+                const size_t rowoff = ((size_t)bl * d.nx + (i0 + g)) * d.ny;
+                const V2* xr = reinterpret_cast<const V2*>(x + rowoff) + t;
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    xq[j] = xr[TPB * j];
+                    if constexpr (BEAM) bq[j] = reinterpret_cast<const V2*>(beam + rowoff)[t + TPB * j];
+                }
+            }
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if constexpr (P::PARK) park[j * NT + tid] = vv[j]; else ev[j] = vv[j];
@@ -2103,6 +2122,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     }
                 }
                 if constexpr (P::NXT) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
+            } else if constexpr ((PFB_INV_EARLY & 1) != 0 && MODE == 2 && OPF) {
+#pragma unroll
+                for (int j = 0; j < E / NPA; ++j) rq[j] = dr2[TPB * j];
             }
             __syncthreads();
             STAMP(2, sit, 8);
@@ -2113,10 +2135,13 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     constexpr int K = decltype(k)::value;
                     if constexpr (MODE == 2 && OPF) {
                         if constexpr (K < NPA) {        // dot_with2 rows first: the epilogue waits for them
+                            if constexpr (!((PFB_INV_EARLY & 1) && K == 0))
 #pragma unroll
                             for (int j = (K * E) / NPA; j < ((K + 1) * E) / NPA; ++j) { if constexpr ((PFB_INV_ABL & 2) == 0) rq[j] = dr2[TPB * j]; else { rq[j].x = (T)(t - j); rq[j].y = (T)2; } }
                         } else {                        // the next tile's even-bin pieces stay in flight past the epilogue
                             constexpr int KK = K - NPA;
+                            if constexpr ((PFB_INV_EARLY & 8) != 0) { if constexpr (K == NP - 1) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y); }
+                            else
                             inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
                         }
                     } else if constexpr (P::NXT) {
