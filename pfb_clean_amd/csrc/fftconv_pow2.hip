@@ -2211,6 +2211,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 [[maybe_unused]] V2 bb;
                 if constexpr (OPF) { xx = xq[j]; if constexpr (BEAM) bb = bq[j]; }
                 else if constexpr (P::HOIST) { xx = xh[j]; if constexpr (BEAM) bb = bh[j]; }
+                else if constexpr ((PFB_INV_ABL & 2) != 0) { xx.x = (T)(t + j); xx.y = (T)1; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 else { xx = xr_e[TPB * j]; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 if constexpr (BEAM) {
                     val.x = zz.x * scale * bb.x + sigmainv * xx.x;
@@ -2220,6 +2221,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     val.y = zz.y * scale + sigmainv * xx.y;
                 }
                 if constexpr (SPR && P::PARK) { if (dst) ov[j] = val; else orow[TPB * j] = val; }
+                else if constexpr ((PFB_INV_ABL & 4) != 0 && MODE >= 1) { }          // (the inner products keep val alive)
                 else orow[TPB * j] = val;
                 // operands read in place (!OPF): a few samples at a time, or every x / dot_with2 load of the tile is
                 // hoisted to the top of the loop and spills
@@ -2228,7 +2230,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
                         V2 d2;
-                        if constexpr (OPF) d2 = rq[j]; else if constexpr (P::HOIST) d2 = rh[j]; else d2 = dr_e[TPB * j];
+                        if constexpr (OPF) d2 = rq[j]; else if constexpr (P::HOIST) d2 = rh[j];
+                        else if constexpr ((PFB_INV_ABL & 2) != 0) { d2.x = (T)(t - j); d2.y = (T)2; }
+                        else d2 = dr_e[TPB * j];
                         acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
                     }
                     acc[2] += (double)val.x * (double)val.x + (double)val.y * (double)val.y;
