@@ -171,6 +171,19 @@ __device__ __forceinline__ Blk<T, NVB> loadb_nt(const cplx<T>* src) {
     return b;
 }
 
+#ifndef PFB_FWD_ABL             // ablation builds of k_row_fwd_pow2q (timing only, results are wrong): 1 no next-tile rows, 4 no stores
+#define PFB_FWD_ABL 0           // of the sweeps, 8 no transforms
+#endif
+template <typename T, int NVB>
+__device__ __forceinline__ void storeb(cplx<T>* dst, const Blk<T, NVB>& b);
+// the strided stores of the forward sweeps (an ablation build keeps the values alive without the memory operation)
+template <typename T, int NVB>
+__device__ __forceinline__ void storeb_sweep(cplx<T>* dst, const Blk<T, NVB>& b) {
+    if constexpr ((PFB_FWD_ABL & 4) != 0) {
+#pragma unroll
+        for (int c = 0; c < NVB; ++c) asm volatile("" :: "v"(b.c[c].x), "v"(b.c[c].y));
+    } else storeb<T, NVB>(dst, b);
+}
 template <typename T, int NVB>
 __device__ __forceinline__ void storeb(cplx<T>* dst, const Blk<T, NVB>& b) {
     *reinterpret_cast<Blk<T, NVB>*>(dst) = b;
@@ -1222,7 +1235,7 @@ __device__ __forceinline__ void post_steps(const cplx<T>* zr, const cplx<T>* ltm
             o.c[h] = T(0.5) * addrot<false>(addc(zv, zm), w * subc(zv, zm));
             if (!valid) o.c[h] = cplx<T>(0, 0);
         }
-        storeb<T, NVB>(Tp + (size_t)b * nx * NVB, o);
+        storeb_sweep<T, NVB>(Tp + (size_t)b * nx * NVB, o);
         __builtin_amdgcn_sched_barrier(0);         // keep the sweeps' LDS reads from piling up (spills)
         post_steps<T, L, PAR, K + 1, NIT, Hook>(zr, ltm, wq1, Tp, nx, bi, hook);
     }
@@ -1257,7 +1270,7 @@ __device__ __forceinline__ void post_steps_lin(const cplx<T>* const (&za)[FastCf
             if constexpr (PAR == 0 && K == 0) { if (first0 && h == 0) zm = zv; }      // m = 0: both are z[0]
             o.c[h] = T(0.5) * addrot<false>(addc(zv, zm), w * subc(zv, zm));
         }
-        storeb<T, NVB>(ub + (size_t)K * ustep + voff, o);
+        storeb_sweep<T, NVB>(ub + (size_t)K * ustep + voff, o);
         __builtin_amdgcn_sched_barrier(0);
         post_steps_lin<T, L, PAR, K + 1, NREG, Hook>(za, zb, lw, wq1, ub, ustep, voff, first0, hook);
     }
@@ -1298,7 +1311,7 @@ __device__ __forceinline__ void fwdp_post_lin(const cplx<T>* zr, const cplx<T>* 
         o.c[0] = T(0.5) * addrot<false>(addc(z0, z0), cplx<T>(T(-1), T(0)) * subc(z0, z0));
 #pragma unroll
         for (int h = 1; h < NVB; ++h) o.c[h] = cplx<T>(0, 0);
-        storeb<T, NVB>(ub + (size_t)(NBP - 1) * nx * NVB + (unsigned)(i0 + rr) * NVB, o);
+        storeb_sweep<T, NVB>(ub + (size_t)(NBP - 1) * nx * NVB + (unsigned)(i0 + rr) * NVB, o);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1433,6 +1446,14 @@ k_row_fwd_pow2p(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
 }
 
 // ------------------------------------------- row forward, persistent, parities in sequence
+template <int NP, typename H> __device__ __forceinline__ void fwd_abl_hooks(H&& h) {
+    if constexpr (NP > 0) { fwd_abl_hooks<NP - 1>(h); h(std::integral_constant<int, NP - 1>{}); }
+}
+template <typename F, typename V, typename C, typename H>
+__device__ __forceinline__ void fwd_run(V& vv, C* lds, int t, const C* ltw, H&& h) {
+    if constexpr ((PFB_FWD_ABL & 8) != 0) fwd_abl_hooks<F::NPASS>(h);
+    else F::template run<false>(vv, lds, t, ltw, h);
+}
 // k_row_fwd_pow2p above runs the even-bin and the odd-bin transform of a tile together and then the two
 // post-processing sweeps; the next tile's rows are requested in one burst between them, which parks all 16 waves at
 // issue (profiles/r02_a_phase_stamps_*: 8.0 of 28 us per trip, and the 9.3 us of the transforms run with NOTHING in
@@ -1492,7 +1513,7 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
                 vv[j] = cplx<T>(xa[j].x, xa[j].y);
             }
             STAMP(0, sit, 1);
-            F::template run<false>(vv, lds, t, ltw);
+            if constexpr ((PFB_FWD_ABL & 8) == 0) F::template run<false>(vv, lds, t, ltw);
             STAMP(0, sit, 2);
         }
         {
@@ -1541,11 +1562,12 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
             const V2* xr = reinterpret_cast<const V2*>(x + offn) + t;
             const V2* br = BEAM ? reinterpret_cast<const V2*>(beam + offn) + t : nullptr;
             // the first exchange of this transform waits (barrier) for the even-bin sweep's LDS reads
-            F::template run<false>(vv, lds, t, ltw, [&](auto k) {
+            fwd_run<F>(vv, lds, t, ltw, [&](auto k) {
                 constexpr int K = decltype(k)::value;
 #pragma unroll
                 for (int j = (K * E) / NP; j < ((K + 1) * E) / NP; ++j) {
-                    xa[j] = xr[TPB * j];
+                    if constexpr ((PFB_FWD_ABL & 1) != 0) { xa[j].x = (T)(t + j); xa[j].y = (T)1; }
+                    else xa[j] = xr[TPB * j];
                     if constexpr (BEAM) ba[j] = br[TPB * j];
                 }
             });
