@@ -1768,6 +1768,9 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
 // global load may sit between the request and the FFT's end (s_waitcnt vmcnt retires in
 // order), so w_M^n lives in the LDS as well (w_Q^(2m+1) = w_M^m * w_Q), and the even-bin
 // result is parked in the LDS (not registers) while the odd-bin transform runs.
+#ifndef PFB_INV_BARUP
+#define PFB_INV_BARUP 1
+#endif
 template <typename T, int L, int E>
 struct InvP {
     using C = RowCfg<T, L, true>;
@@ -1819,6 +1822,11 @@ struct InvP {
     // HOIST (fp32 NXE): all operand rows of the tile requested at once behind the combine loop (the even-bin result is dead
     // by then), the next tile's even-bin pieces half way through the loop that consumes them, in the registers it has freed
     static constexpr bool HOIST = NXE && sizeof(T) == 4;
+    // BARUP: the barrier between the odd-bin transform's last exchange and the next tile's scatter sits right behind that
+    // transform instead of at the top of the next trip (8 x 4096^2 fp32 0.6293 -> 0.6229 ms, 2 x 8192^2 fp64 1.673 -> 1.643); not
+    // for the fp32 tiles that request a tile's pieces at the top of its own trip -- there the barrier was the only thing
+    // those loads were in flight across (0.706 -> 0.732)
+    static constexpr bool BARUP = PFB_INV_BARUP && (NXT || sizeof(T) == 8);
     static constexpr int NTM = SMT ? F::TPB : L;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
@@ -2064,7 +2072,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
-            __syncthreads();
+            if (!P::BARUP || sit == 0) __syncthreads();      // (BARUP: the barrier that protects lds0 sits behind the odd-bin transform)
             STAMP(2, sit, 1);
             inv_scatter<T, L, E, 0>(y, lds0 + (size_t)rr * P::STRIDE, bi);
             STAMP(2, sit, 2);
@@ -2112,6 +2120,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     if constexpr (BEAM) bq[j] = reinterpret_cast<const V2*>(beam + rowoff)[t + TPB * j];
                 }
             }
+            if constexpr (P::BARUP && (PFB_INV_BARUP & 2) != 0) __syncthreads();   // (the even transform's readers are done: before the park, not behind it)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 if constexpr (P::PARK) park[j * NT + tid] = vv[j]; else ev[j] = vv[j];
@@ -2122,7 +2131,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             const int tid = launder((int)threadIdx.x);
             const int g = tid / TPB, t = tid % TPB, rr = tid % G, bi = tid / G;
             cplx<T>* lds = lds0 + (size_t)g * P::STRIDE;
-            __syncthreads();
+            if constexpr (!(P::BARUP && (PFB_INV_BARUP & 2) != 0)) __syncthreads();
             STAMP(2, sit, 6);
             inv_scatter<T, L, E, 1>(y, lds0 + (size_t)rr * P::STRIDE, bi);
             STAMP(2, sit, 7);
@@ -2174,6 +2183,10 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 F::template run<true>(vv, lds, t, ltw);
             }
             STAMP(2, sit, 10);
+            // the last exchange's readers are done BEFORE the epilogue instead of at the top of the next trip: the waves are
+            // still in step here (cheap), and a wave that is through with its epilogue scatters the next tile's pieces while
+            // the others finish theirs -- the skew is absorbed by the barrier behind the scatter
+            if constexpr (P::BARUP) __syncthreads();
         }
         if constexpr (P::NXE && !P::HOIST) {
             const int tid = launder((int)threadIdx.x);
