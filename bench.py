@@ -252,7 +252,7 @@ def extra_configs(ctx):
         ("C1_1024x1_f32", "pcg", dict(size=1024, bands=1, dtype='f32', steps=50, warmup=5, repeats=3)),
         ("C2_4096x1_f32", "pcg", dict(size=4096, bands=1, dtype='f32', steps=50, warmup=5, repeats=3)),
         ("C4_pd_2048x4_f32", "pd", dict(size=2048, bands=4, dtype='f32', steps=20, warmup=3, repeats=3)),
-        ("C5_shard_8192x2_f64", "pcg", dict(size=8192, bands=2, dtype='f64', steps=10, warmup=2, repeats=3)),
+        ("C5_shard_8192x2_f64", "pcg", dict(size=8192, bands=2, dtype='f64', steps=50, warmup=2, repeats=3)),
     ]
     res = {}
     for name, workload, kw in specs:
