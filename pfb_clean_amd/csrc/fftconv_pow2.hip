@@ -2330,6 +2330,20 @@ int pow2_set_stamp(unsigned long long* buf) {
 #define PFB_POW2_SIZES(X) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096) X(8192)
 
 // -------------------------------------------------------------------- host side
+// Grid of the persistent column kernel k_col_pow2p: not all `maxgrid` resident workgroups but as many as give every one of them the same number
+// of trips.  `need` is rarely a multiple of the CU count (a band is 2^k + 1 column blocks), and a last trip with a handful
+// of workgroups runs at their latency while the rest of the chip idles -- the same work on slightly fewer workgroups is
+// bandwidth bound to the end: col 0.816 -> 0.800 ms at 8 x 4096^2 fp32 (253 instead of 256 workgroups), 45.5 -> 42.6 us
+// at 1 x 2048^2 (342 instead of 512), 129.3 -> 126.5 us at 1 x 4096^2 (228), 0.889 -> 0.861 ms at 4 x 4096^2 fp64.  Only for
+// that kernel (the row kernels' grids divide evenly at the usual sizes, the two-level column kernel loses).  PFB_GRID_BALANCE=0: off.
+static inline int balanced_grid(int need, int maxgrid) {
+    if (need <= maxgrid) return need;
+    static const bool on = [] { const char* e = getenv("PFB_GRID_BALANCE"); return !e || atoi(e); }();
+    if (!on) return maxgrid;
+    const int trips = (need + maxgrid - 1) / maxgrid;
+    return (need + trips - 1) / trips;
+}
+
 struct FastTables {            // device tables owned by the plan (stored behind p->fast_tables)
     void* ptw_col;
     void* ptwc_col;            // compact (w only) table of the column transform, copied to LDS
@@ -2613,9 +2627,10 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
             const int wg_lds = (int)(((size_t)160 * 1024) / CX::LDS);
             int wg_per_cu = (8 * 64) / (GX * FX::TPB) > 0 ? (8 * 64) / (GX * FX::TPB) : 1;
             if (wg_per_cu > wg_lds) wg_per_cu = wg_lds > 0 ? wg_lds : 1;
-            int grid = ft->num_cu * wg_per_cu;
             const int need = (nitems + GX - 1) / GX;
-            if (grid > need) grid = need;
+            // (not balanced_grid: this kernel is bound by the issue of its transforms, every workgroup counts --
+            // 2.003 -> 2.047 ms fp64, 1.110 -> 1.128 fp32 with 253 / 249 instead of 256)
+            const int grid = need < ft->num_cu * wg_per_cu ? need : ft->num_cu * wg_per_cu;
             const size_t ldsx = CX::LDS;
 #define PFB_COLX(NTV)                                                                                          \
             hipLaunchKernelGGL((k_col_pow2x<T, H, ECOLX, NTV>), dim3(grid), dim3(GX * FX::TPB), ldsx, st,      \
@@ -2641,9 +2656,8 @@ static void launch_col(pfb_conv_plan* p, const FastTables* ft, int band0, int nb
         // col 0.995 -> 0.987 ms, row_inv 0.666 -> 0.660 ms at 8 x 4096^2 fp32.  PFB_COL_REV=0 turns it off.
         static const bool rev = [] { const char* e = getenv("PFB_COL_REV"); return !e || atoi(e); }();
         const int wg_per_cu = (8 * 64) / (GC * F::TPB) > 0 ? (8 * 64) / (GC * F::TPB) : 1;
-        int grid = ft->num_cu * wg_per_cu;
         const int need = (nitems + GC - 1) / GC;
-        if (grid > need) grid = need;
+        const int grid = balanced_grid(need, ft->num_cu * wg_per_cu);
         // second exchange buffer set when ONE workgroup per CU is resident anyway and it fits: col 0.98 ->
         // 0.96 ms at 8 x 4096^2 fp32, 1.16 -> 1.10 ms at 4 x 4096^2 fp64; with two workgroups per CU (H = 2048)
         // the doubled LDS costs residency (fp64 0.245 -> 0.304 ms).  PFB_COL_DB=0 turns it off.
