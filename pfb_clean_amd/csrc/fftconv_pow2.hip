@@ -171,6 +171,12 @@ __device__ __forceinline__ Blk<T, NVB> loadb_nt(const cplx<T>* src) {
     return b;
 }
 
+#ifndef PFB_FWD_ROT
+#define PFB_FWD_ROT 0
+#endif
+#ifndef PFB_COL_ROT
+#define PFB_COL_ROT 0
+#endif
 #ifndef PFB_FWD_ABL             // ablation builds of k_row_fwd_pow2q (timing only, results are wrong): 1 no next-tile rows, 4 no stores
 #define PFB_FWD_ABL 0           // of the sweeps, 8 no transforms
 #endif
@@ -518,7 +524,13 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
         return psf_l + (size_t)(band0 + bstep * bl) * psf_band + ((size_t)blk * 2 * H + t) * NVB;
     };
 
-    int item = blockIdx.x * GC + g;
+    // PFB_COL_ROT: the workgroup -> item map rotates by that many workgroups per trip (see k_row_inv_pow2p)
+    auto item_of = [&](int it) -> int {
+        if constexpr (PFB_COL_ROT != 0)
+            return (int)(((unsigned)blockIdx.x + (unsigned)it * (unsigned)PFB_COL_ROT) % gridDim.x) * GC + g + it * stride;
+        else return blockIdx.x * GC + g + it * stride;
+    };
+    int item = item_of(0);
     Blk<T, NVB> an[E];
     Blk<T, NVB> q[E];
     {
@@ -540,14 +552,14 @@ k_col_pow2p(cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ psf_l,
     }
     __syncthreads();                                            // twiddle table visible
 #pragma unroll 1
-    for (int it = 0; it < niter; ++it, item += stride) {
+    for (int it = 0; it < niter; ++it, item = item_of(it)) {
         STAMP(1, it, 0);
         const bool active = item < nitems;
         cplx<T>* col = col_of(active ? item : 0);
         const cplx<T>* pe = psf_of(active ? item : 0);
         const cplx<T>* po = pe + (size_t)H * NVB;
         // next item (clamped: a trip past the end re-reads a valid block and drops it)
-        const int nxt = item + stride;
+        const int nxt = item_of(it + 1);
         const bool nact = nxt < nitems;
         const cplx<T>* cn = col_of(nact ? nxt : (active ? item : 0));
         const cplx<T>* pen = psf_of(nact ? nxt : (active ? item : 0));
@@ -1498,7 +1510,14 @@ k_row_fwd_pow2q(const T* __restrict__ x, const T* __restrict__ beam, cplx<T>* __
     __syncthreads();                                    // tables visible
     for (int sit = 0;; ++sit) {
         STAMP(0, sit, 0);
-        const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        int vbn;
+        if constexpr (PFB_FWD_ROT != 0) {      // (see k_row_inv_pow2p: the workgroup -> tile map rotates per trip)
+            const int s1 = sit + 1;
+            const int cand = (int)(((unsigned)blockIdx.x + (unsigned)s1 * (unsigned)PFB_FWD_ROT) % gridDim.x) + s1 * (int)gridDim.x;
+            vbn = cand < ntiles ? cand : vb;
+        } else {
+            vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        }
         const int bl = vb / tiles_per_band, i0 = P::tile_row(vb - bl * tiles_per_band, tiles_per_band);
         cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
         cplx<T> vv[E];
@@ -1770,6 +1789,16 @@ k_row_inv_pow2(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twQ,
 // result is parked in the LDS (not registers) while the odd-bin transform runs.
 #ifndef PFB_INV_BARUP
 #define PFB_INV_BARUP 1
+#endif
+// PFB_INV_ROT: the workgroup -> tile map of k_row_inv_pow2p rotates by that many workgroups per trip.  With the static map
+// (tile = workgroup + trip x grid) a workgroup -- and its whole XCD, workgroup b runs on XCD b mod 8 -- reads the SAME 128 bytes
+// of every 1-KB stretch of a column block for the whole launch, and one XCD ran 13-15 % behind the others from the first trip to
+// the last (profiles/r03_z_phase_stamps_4096x8_f32.md, per-XCD table): the launch lasts as long as its slowest workgroup.
+// Rotating gives every workgroup every row residue in turn: 8 x 4096^2 fp32 0.614 -> 0.541 ms, 4 x 4096^2 fp64 0.716 -> 0.581,
+// 2 x 8192^2 fp64 1.644 -> 1.450, fp32 0.749 -> 0.679, with beam 0.720 -> 0.635; bit-identical results
+// (profiles/r03_ab_tile_rotation.md).  The forward rows and the column kernel show no such spread and no effect.
+#ifndef PFB_INV_ROT
+#define PFB_INV_ROT 3
 #endif
 template <typename T, int L, int E>
 struct InvP {
@@ -2056,7 +2085,16 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     V2* oprev = nullptr;
     for (int sit = 0;; ++sit) {
         STAMP(2, sit, 0);
-        const int vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        int vbn;
+        if constexpr (PFB_INV_ROT != 0) {
+            // the workgroup -> tile map rotates by PFB_INV_ROT workgroups per trip: over its trips a workgroup sees the row
+            // groups of every XCD, not always the same 128 bytes of each 1-KB stretch of a column block
+            const int s1 = sit + 1;
+            const int cand = (int)(((unsigned)blockIdx.x + (unsigned)s1 * (unsigned)PFB_INV_ROT) % gridDim.x) + s1 * (int)gridDim.x;
+            vbn = cand < ntiles ? cand : vb;
+        } else {
+            vbn = vb + (int)gridDim.x < ntiles ? vb + (int)gridDim.x : vb;   // last tile: harmless repeat
+        }
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;

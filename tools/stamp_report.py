@@ -93,3 +93,22 @@ for kid, (name, phases) in NAMES.items():
     nxt = (a[:, 1:, 0] - a[:, :-1, 0])[live[:, 1:] & live[:, :-1]]
     if nxt.size:
         print(f"| trip to trip | {nxt.mean():.2f} | {np.percentile(nxt, 10):.2f} | {np.percentile(nxt, 90):.2f} |")
+
+# per-XCD spread of the trip-to-trip time (workgroup b runs on XCD b % 8 in launch order): a systematic difference between
+# XCDs is what a dynamic tile queue could balance
+print("## trip-to-trip time by XCD (mean microseconds over the stamped trips of the workgroups b = xcd mod 8)")
+print("| kernel | " + " | ".join(f"xcd {x}" for x in range(8)) + " | slowest workgroup / mean |")
+print("|---|" + "---|" * 9)
+for kid in (0, 1, 2):
+    name, _ = NAMES[kid]
+    a = st[kid]
+    ok = (a[:, :, 0] > 0).all(axis=1)
+    idx = np.nonzero(ok)[0]
+    if idx.size == 0:
+        continue
+    t2t = (a[:, 1:, 0] - a[:, :-1, 0]).mean(axis=1)                      # per workgroup
+    cells = []
+    for x in range(8):
+        sel = idx[idx % 8 == x]
+        cells.append(f"{t2t[sel].mean():.2f}" if len(sel) else "-")
+    print(f"| {name} | " + " | ".join(cells) + f" | {t2t[idx].max() / t2t[idx].mean():.3f} |")
