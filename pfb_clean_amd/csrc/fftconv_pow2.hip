@@ -1847,7 +1847,12 @@ struct InvP {
 #ifndef PFB_INV_NXE
 #define PFB_INV_NXE 0           // measured: 1.955 vs 1.639 ms per 2 x 8192^2 fp64 (the pieces queue behind the epilogue's own loads): off
 #endif
-    static constexpr bool NXE = !NXT && PFB_INV_NXE && (sizeof(T) == 8 || PFB_INV_NXE > 1);
+    // HOIST32 (default): the fp32 16-element tiles (4096-point rows) read their operand rows in two batches of 8 samples and
+    // request the next tile's even-bin pieces behind the second batch: 2 x 8192^2 fp32 0.682 -> 0.665 ms (no change with beam)
+#ifndef PFB_INV_HOIST32
+#define PFB_INV_HOIST32 1
+#endif
+    static constexpr bool NXE = !NXT && ((PFB_INV_NXE && (sizeof(T) == 8 || PFB_INV_NXE > 1)) || (PFB_INV_HOIST32 && sizeof(T) == 4));
     // HOIST (fp32 NXE): all operand rows of the tile requested at once behind the combine loop (the even-bin result is dead
     // by then), the next tile's even-bin pieces half way through the loop that consumes them, in the registers it has freed
     static constexpr bool HOIST = NXE && sizeof(T) == 4;
@@ -1855,7 +1860,7 @@ struct InvP {
     // transform instead of at the top of the next trip (8 x 4096^2 fp32 0.6293 -> 0.6229 ms, 2 x 8192^2 fp64 1.673 -> 1.643); not
     // for the fp32 tiles that request a tile's pieces at the top of its own trip -- there the barrier was the only thing
     // those loads were in flight across (0.706 -> 0.732)
-    static constexpr bool BARUP = PFB_INV_BARUP && (NXT || sizeof(T) == 8);
+    static constexpr bool BARUP = PFB_INV_BARUP && (NXT || sizeof(T) == 8 || (HOIST && PFB_INV_HOIST32 > 1));
     static constexpr int NTM = SMT ? F::TPB : L;
     static constexpr size_t LDS = 384 + sizeof(cplx<T>) * ((size_t)PTWP + NTM + (size_t)G * STRIDE + (PARK ? (size_t)G * L : 0));
     static constexpr bool OK = LDS <= (size_t)160 * 1024 && !C::WAVE && (!SMT || 32 * F::TPB == 2 * L) &&
