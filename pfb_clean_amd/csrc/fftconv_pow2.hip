@@ -2052,6 +2052,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     using P = InvP<T, L, E>;
     using F = typename P::F;
     constexpr int TPB = F::TPB, G = P::G, NT = P::NT;
+    // (the batched-operand variant of the fp32 16-element tiles keeps 12 B of scratch with beam + two inner products: that
+    // instantiation stays on the plain order -- a tile's pieces requested at the top of its own trip)
+    constexpr bool NXEK = P::NXE && !(P::HOIST && BEAM && MODE == 2), HOISTK = P::HOIST && NXEK;
     constexpr int NP = F::NPASS, NPA = NP / 2 > 0 ? NP / 2 : 1, NPB = NP - NPA > 0 ? NP - NPA : 1;
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2080,7 +2083,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     // OPF kernels keep the NEXT tile's even-bin pieces in flight across the epilogue; without the registers for that
     // (!OPF: 16 elements per thread) a tile's even-bin pieces are requested at the top of its own trip instead
-    if constexpr (P::NXT || P::NXE)
+    if constexpr (P::NXT || NXEK)
         inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
     // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
@@ -2103,7 +2106,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
-        if constexpr (!P::NXT && !P::NXE) {
+        if constexpr (!P::NXT && !NXEK) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tb, d.nx, i0, tid % G, tid / G, y);
         }
@@ -2231,7 +2234,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
             // the others finish theirs -- the skew is absorbed by the barrier behind the scatter
             if constexpr (P::BARUP) __syncthreads();
         }
-        if constexpr (P::NXE && !P::HOIST) {
+        if constexpr (NXEK && !HOISTK) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bln) * d.T_band, d.nx, i0n, tid % G, tid / G, y);
         }
@@ -2256,7 +2259,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 for (int j = 0; j < E; ++j) vv[j] = ev[j] + mulc(vv[j], P::tw_row(ltm, t, j));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            [[maybe_unused]] V2 xh[P::HOIST ? E : 1], rh[(P::HOIST && MODE == 2) ? E : 1], bh[(P::HOIST && BEAM) ? E : 1];
+            [[maybe_unused]] V2 xh[HOISTK ? E : 1], rh[(HOISTK && MODE == 2) ? E : 1], bh[(HOISTK && BEAM) ? E : 1];
 
 #pragma unroll
             for (int j = 0; j < E; ++j) {
@@ -2267,7 +2270,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                     if constexpr (P::PARK) e0 = park[j * NT + tid]; else e0 = ev[j];
                     zz = e0 + mulc(vv[j], P::tw_row(ltm, t, j));
                 }
-                if constexpr (P::HOIST) {
+                if constexpr (HOISTK) {
                     // operand rows in batches of HB samples; behind the LAST batch the next tile's even-bin pieces (in order:
                     // nothing the epilogue still waits for is queued behind them)
                     constexpr int HB = PFB_INV_HOIST_B;
@@ -2288,7 +2291,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 V2 xx;
                 [[maybe_unused]] V2 bb;
                 if constexpr (OPF) { xx = xq[j]; if constexpr (BEAM) bb = bq[j]; }
-                else if constexpr (P::HOIST) { xx = xh[j]; if constexpr (BEAM) bb = bh[j]; }
+                else if constexpr (HOISTK) { xx = xh[j]; if constexpr (BEAM) bb = bh[j]; }
                 else if constexpr ((PFB_INV_ABL & 2) != 0) { xx.x = (T)(t + j); xx.y = (T)1; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 else { xx = xr_e[TPB * j]; if constexpr (BEAM) bb = br_e[TPB * j]; }
                 if constexpr (BEAM) {
@@ -2303,12 +2306,12 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                 else orow[TPB * j] = val;
                 // operands read in place (!OPF): a few samples at a time, or every x / dot_with2 load of the tile is
                 // hoisted to the top of the loop and spills
-                if constexpr (!OPF && !P::HOIST) { if (sizeof(T) == 4 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (!OPF && !HOISTK) { if (sizeof(T) == 4 && (j & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (MODE >= 1) {
                     acc[0] += (double)xx.x * (double)val.x + (double)xx.y * (double)val.y;
                     if constexpr (MODE == 2) {
                         V2 d2;
-                        if constexpr (OPF) d2 = rq[j]; else if constexpr (P::HOIST) d2 = rh[j];
+                        if constexpr (OPF) d2 = rq[j]; else if constexpr (HOISTK) d2 = rh[j];
                         else if constexpr ((PFB_INV_ABL & 2) != 0) { d2.x = (T)(t - j); d2.y = (T)2; }
                         else d2 = dr_e[TPB * j];
                         acc[1] += (double)d2.x * (double)val.x + (double)d2.y * (double)val.y;
