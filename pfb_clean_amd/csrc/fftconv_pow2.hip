@@ -1835,8 +1835,8 @@ struct InvP {
     // NXT: the NEXT tile's even-bin pieces are requested during the odd-bin transform and stay in flight across the
     // epilogue (always with OPF; without it only where registers remain: the 512-thread fp64 tiles have 256)
 #ifndef PFB_INV_NXT64
-#define PFB_INV_NXT64 0          // measured a tie (1.612 / 1.618 ms): the lighter variant
-#endif
+#define PFB_INV_NXT64 1          // 2 x 8192^2 fp64: 1.376 -> 1.195 ms (239 VGPRs, no scratch).  It had measured a tie (1.612 / 1.618)
+#endif                           // while one XCD set the pace of every variant (PFB_INV_ROT)
     static constexpr bool NXT = OPF || (PFB_INV_NXT64 && sizeof(T) == 8);
     // NXE: neither -- but the next tile's even-bin pieces are requested at the START of the epilogue (the transforms are
     // over, their temporaries gone) instead of at the top of the next trip, where they were waited for right away
