@@ -2055,6 +2055,9 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     // (the batched-operand variant of the fp32 16-element tiles keeps 12 B of scratch with beam + two inner products: that
     // instantiation stays on the plain order -- a tile's pieces requested at the top of its own trip)
     constexpr bool NXEK = P::NXE && !(P::HOIST && BEAM && MODE == 2), HOISTK = P::HOIST && NXEK;
+    // (likewise the fp64 16-element tiles without the per-pass request schedule -- PFB_SPREAD=0, an A/B fallback -- keep 12 B
+    // of scratch with the next tile's pieces prefetched: that instantiation requests them at the top of the trip)
+    constexpr bool NXTK = P::NXT && (P::OPF || SPR);
     constexpr int NP = F::NPASS, NPA = NP / 2 > 0 ? NP / 2 : 1, NPB = NP - NPA > 0 ? NP - NPA : 1;
     using V2 = typename vec2<T>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2083,7 +2086,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
     Blk<T, P::NVB> y[P::NITE];
     // OPF kernels keep the NEXT tile's even-bin pieces in flight across the epilogue; without the registers for that
     // (!OPF: 16 elements per thread) a tile's even-bin pieces are requested at the top of its own trip instead
-    if constexpr (P::NXT || NXEK)
+    if constexpr (NXTK || NXEK)
         inv_issue<T, L, E, 0>(Tw + (size_t)(band0 + bl) * d.T_band, d.nx, i0, threadIdx.x % G, threadIdx.x / G, y);
     double acc[3] = {0.0, 0.0, 0.0};
     // deferred stores (SPR, fp32): a tile's output rows stay in registers and are written two per pass of the NEXT
@@ -2106,7 +2109,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
         int bln, i0n;
         tile(vbn, bln, i0n);
         const cplx<T>* Tb = Tw + (size_t)(band0 + bl) * d.T_band;
-        if constexpr (!P::NXT && !NXEK) {
+        if constexpr (!NXTK && !NXEK) {
             const int tid = launder((int)threadIdx.x);
             inv_issue<T, L, E, 0>(Tb, d.nx, i0, tid % G, tid / G, y);
         }
@@ -2198,7 +2201,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                         for (int j = 0; j < E; ++j) bq[j] = br[TPB * j];
                     }
                 }
-                if constexpr (P::NXT) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
+                if constexpr (NXTK) inv_issue<T, L, E, 0>(Tbn, d.nx, i0n, rr, bi, y);
             } else if constexpr ((PFB_INV_EARLY & 1) != 0 && MODE == 2 && OPF) {
 #pragma unroll
                 for (int j = 0; j < E / NPA; ++j) rq[j] = dr2[TPB * j];
@@ -2221,7 +2224,7 @@ k_row_inv_pow2p(const cplx<T>* __restrict__ Tw, const cplx<T>* __restrict__ twM,
                             else
                             inv_issue_slice<T, L, E, 0, (KK * P::NITE) / NPB, ((KK + 1) * P::NITE) / NPB>(Tbn, d.nx, i0n, rr, bi, y);
                         }
-                    } else if constexpr (P::NXT) {
+                    } else if constexpr (NXTK) {
                         inv_issue_slice<T, L, E, 0, (K * P::NITE) / NP, ((K + 1) * P::NITE) / NP>(Tbn, d.nx, i0n, rr, bi, y);
                     }
                 });
